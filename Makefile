@@ -1,0 +1,29 @@
+# Builds the product library (HIP, gfx950) and the test-side oracle.
+#   make lib      -> opencl_pathtracer_amd/lib/libptmi.so      (hipcc, cross-compiles without a GPU)
+#   make oracle   -> oracle/build/libpt_oracle.so              (gcc, CPU checker; test infrastructure)
+#   make ref      -> oracle/_ref/*                             (only where /root/reference exists)
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+CSRC       := opencl_pathtracer_amd/csrc
+LIBDIR     := opencl_pathtracer_amd/lib
+# -ffp-contract=off: the numerics contract forbids fused multiply-add
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+LIB_SRCS   := $(CSRC)/kernels.hip $(CSRC)/ptmi_api.cpp $(CSRC)/bvh_build.cpp
+LIB_HDRS   := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp)
+
+.PHONY: all lib oracle ref clean
+all: lib oracle
+
+lib: $(LIBDIR)/libptmi.so
+$(LIBDIR)/libptmi.so: $(LIB_SRCS) $(LIB_HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared $(LIB_SRCS) -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf $(LIBDIR) oracle/build oracle/_ref

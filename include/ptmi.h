@@ -1,0 +1,170 @@
+/*
+ * ptmi.h - C ABI of the MI355X path-tracing integrator (libptmi.so).
+ *
+ * Drop-in boundary: the three functions the reference's orchestration calls on
+ * its device backend, Controleur/PathTracer_OpenCL.h:17-19
+ *     OpenCL_SetupContext(GlobalVars&, Sampler)           (PathTracer_OpenCL.cpp:316-402)
+ *     OpenCL_InitializeMemory(GlobalVars&)                (PathTracer_OpenCL.cpp:149-198)
+ *     OpenCL_RunKernel(GlobalVars&, cb, nImages, t1,t2,t3)(PathTracer_OpenCL.cpp:56-140)
+ * called once each, in that order, from PathTracer_Main (PathTracer.cpp:74,76,82),
+ * plus the host BVH build that produces one of their inputs
+ *     BVH_Create(GlobalVars&)                             (PathTracer_BVH.cpp:12-37).
+ * Each entry point below names the reference code it replaces.  The C++ shim
+ * with the reference's own signatures on top of this ABI is
+ * opencl_pathtracer_amd/csrc/PathTracer_HIP.cpp.
+ *
+ * Conventions: plain pointers and sizes, caller-owned host memory,
+ * context-owned device memory, no exceptions; every call returns PTMI_OK (0)
+ * or a negative ptmi_status and leaves a message for ptmi_last_error().
+ * There is NO CPU fallback: without a HIP device every compute entry point
+ * fails with PTMI_ERR_NO_DEVICE.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stdint.h>
+#include "ptmi_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_ABI_VERSION 1
+
+typedef enum ptmi_status {
+    PTMI_OK = 0,
+    PTMI_ERR_INVALID_ARGUMENT = -1, /* null pointer, zero image, bad sampler ... */
+    PTMI_ERR_NO_DEVICE = -2,        /* no HIP device / bad ordinal (reference: "Wrong context.", OpenCL.cpp:359-360) */
+    PTMI_ERR_HIP = -3,              /* a HIP runtime call failed (reference: OpenCL_ErrorHandling, OpenCL.cpp:407-486) */
+    PTMI_ERR_LIMIT = -4,            /* bvh depth >= 30 or lights >= 30 (reference guard, PathTracer.cpp:54-65) */
+    PTMI_ERR_BAD_SCENE = -5,        /* scene arrays inconsistent (index out of range, cyclic bvh ...) */
+    PTMI_ERR_STATE = -6,            /* call order violated (e.g. render before initialize_memory) */
+    PTMI_ERR_UNSUPPORTED = -7       /* feature compiled out / not available in this build */
+} ptmi_status;
+
+typedef struct ptmi_ctx ptmi_ctx;
+
+/* What OpenCL_BuildOptions bakes into the kernel with -D (OpenCL.cpp:292-314),
+ * plus the device choice made in OpenCL_SetupContext (OpenCL.cpp:356-366). */
+typedef struct ptmi_config {
+    uint32_t struct_size;    /* = sizeof(ptmi_config), ABI guard */
+    int32_t device;          /* HIP device ordinal (reference: devices[0]) */
+    uint32_t image_width;    /* -D IMAGE_WIDTH  (globalVars.imageWidth)  */
+    uint32_t image_height;   /* -D IMAGE_HEIGHT (globalVars.imageHeight) */
+    uint32_t ray_max_depth;  /* -D MAX_REFLECTION_NUMBER (globalVars.rayMaxDepth) */
+    uint32_t lights_size;    /* -D LIGHTS_SIZE (globalVars.lightsSize) */
+    uint32_t sampler;        /* PTMI_SAMPLER_* : -D SAMPLE_JITTERED / _RANDOM / _UNIFORM */
+    uint32_t super_sampling; /* -D SUPER_SAMPLING (globalVars.superSampling) */
+    uint32_t flags;          /* PTMI_FLAG_* */
+} ptmi_config;
+
+#define PTMI_FLAG_NO_HISTOGRAMS 1u /* skip the three per-path histogram atomics (FullKernel.cl:1319-1331); totals are still kept */
+
+/* What OpenCL_InitializeMemory copies with CL_MEM_COPY_HOST_PTR and passes as
+ * kernel arguments 1..17 (OpenCL.cpp:165-197).  Arrays are raw dumps of the
+ * ptmi_scene.h structs; a zero-length array may be NULL. */
+typedef struct ptmi_scene {
+    uint32_t struct_size; /* = sizeof(ptmi_scene) */
+    const ptmi_node* bvh;                 uint32_t bvh_size;
+    const ptmi_triangle* triangulation;   uint32_t triangulation_size;
+    const ptmi_light* lights;             uint32_t lights_size;
+    const ptmi_material* materiaux;       uint32_t materiaux_size;
+    const ptmi_texture* textures;         uint32_t textures_size;
+    const ptmi_uchar4* textures_data;     uint32_t textures_data_size;
+    const ptmi_sky* sky;
+    ptmi_float4 camera_position;  /* kernel arg 1 */
+    ptmi_float4 camera_direction; /* kernel arg 2 */
+    ptmi_float4 camera_right;     /* kernel arg 3 */
+    ptmi_float4 camera_up;        /* kernel arg 4 */
+} ptmi_scene;
+
+/* Totals the roofline model is priced from: exact sums of the
+ * reference's per-path counters over everything rendered since the last
+ * ptmi_initialize_memory / ptmi_clear. */
+typedef struct ptmi_counters {
+    uint64_t paths;          /* Kernel_Main invocations that reached the epilogue */
+    uint64_t segments;       /* BVH_IntersectRay calls ("samples": paths x bounces) */
+    uint64_t surface_hits;   /* sum of r.reflectionId = segments that hit geometry */
+    uint64_t shadow_rays;    /* BVH_IntersectShadowRay calls */
+    uint64_t box_tests;      /* sum of numIntersectedBBx incl. shadow rays */
+    uint64_t triangle_tests; /* sum of numIntersectedTri incl. shadow rays */
+} ptmi_counters;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Replaces OpenCL_SetupContext (OpenCL.cpp:316-402): picks the device, creates
+ * the stream and selects the kernel specialisation.  *ctx is NULL on failure. */
+int ptmi_setup_context(ptmi_ctx** ctx, const ptmi_config* config);
+
+/* Replaces OpenCL_InitializeMemory (OpenCL.cpp:149-198): validates the scene,
+ * re-lays it out for the device, uploads it and allocates + ZEROES the
+ * accumulators (the reference leaves them uninitialised, OpenCL.cpp:159-164).
+ * May be called again on the same context with a new scene. */
+int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* scene);
+
+/* Replaces the clSetKernelArg(0, imageId) + clEnqueueNDRangeKernel(W x H) pair
+ * of OpenCL_RunKernel's loop (OpenCL.cpp:85-89), generalised to a range:
+ * renders iterations [first_iteration, first_iteration + n_iterations) for
+ * every pixel and adds them into the accumulators.  Asynchronous on the
+ * context's stream. */
+int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations);
+
+/* clFinish (OpenCL.cpp:89). */
+int ptmi_synchronize(ptmi_ctx* ctx);
+
+/* Replaces the two blocking clEnqueueReadBuffer of every image (OpenCL.cpp:97-98):
+ * image_color = float[4*W*H] sum of radiance, image_ray_nb = float[W*H] sample
+ * count.  Either pointer may be NULL.  Synchronises first. */
+int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb);
+
+/* Replaces the three statistic reads after the loop (OpenCL.cpp:110-112):
+ * ray_depths[ray_max_depth+1], ray_intersected_bbx[5000], ray_intersected_tri[5000].
+ * Any pointer may be NULL. */
+int ptmi_read_statistics(ptmi_ctx* ctx, uint32_t* ray_depths, uint32_t* ray_intersected_bbx,
+                         uint32_t* ray_intersected_tri);
+
+/* Zero accumulators, histograms and counters (new render of the same scene). */
+int ptmi_clear(ptmi_ctx* ctx);
+
+/* Replaces the release block at the end of OpenCL_RunKernel (OpenCL.cpp:120-139). */
+void ptmi_release(ptmi_ctx* ctx);
+
+/* ---- measurement / plumbing -------------------------------------------- */
+
+int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out);
+
+/* Device time of the integrator kernel launches issued by ptmi_render since the
+ * last call, measured with HIP events on the context's stream.  Synchronises. */
+int ptmi_kernel_time(ptmi_ctx* ctx, double* total_ms, uint32_t* n_launches);
+
+/* Run on a caller-owned hipStream_t (passed as void*; NULL = context's own). */
+int ptmi_set_stream(ptmi_ctx* ctx, void* hip_stream);
+
+/* Device pointers of the accumulators (float[4*W*H], float[W*H]) so a caller
+ * that owns a collective library can reduce them in place (multi-GPU spp shards). */
+int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_image_color, void** d_image_ray_nb);
+
+/* Adopt caller-allocated device buffers as accumulators (e.g. torch tensors);
+ * they are NOT zeroed and NOT freed by the context.  Pass NULLs to go back. */
+int ptmi_bind_accumulators(ptmi_ctx* ctx, void* d_image_color, void* d_image_ray_nb);
+
+/* Message of the last failure on this context (ctx may be NULL for failures of
+ * ptmi_setup_context / ptmi_bvh_create).  Never NULL. */
+const char* ptmi_last_error(const ptmi_ctx* ctx);
+
+int ptmi_abi_version(void);
+int ptmi_device_count(void);
+
+/* ---- host-side producer of the bvh input -------------------------------- */
+
+/* Replaces BVH_Create (PathTracer_BVH.cpp:12-37 -> BVH_BuildStructure :109-356):
+ * binned-SAH build, bit-compatible with the reference (same node order, same
+ * in-place reordering of `triangulation`).  `bvh` must hold 2*n-1 nodes.
+ * Host only; needs no device. */
+int ptmi_bvh_create(ptmi_triangle* triangulation, uint32_t triangulation_size, ptmi_node* bvh,
+                    uint32_t* bvh_size, uint32_t* bvh_max_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

@@ -1,0 +1,10 @@
+"""MI355X-native path-tracing integrator: drop-in device backend for adjerbetian/OpenCL_PathTracer scenes.
+
+`backend`  - host-side mirror of the reference's backend interface over the C ABI (libptmi.so)
+`scenes`   - scene construction conventions (Triangle_Create, lights, materials) + BASELINE workloads
+`structs`  - numpy dtypes of the scene contract (include/ptmi_scene.h)
+"""
+from . import structs, scenes, backend  # noqa: F401
+from .backend import Backend, PtmiError, bvh_create, render_scene  # noqa: F401
+
+__all__ = ["structs", "scenes", "backend", "Backend", "PtmiError", "bvh_create", "render_scene"]

@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference's device backend, on top of the C ABI of ``libptmi.so``.
+
+The reference's orchestration drives its backend with three calls
+(``Controleur/PathTracer_OpenCL.h:17-19``, called from ``PathTracer.cpp:74,76,82``)::
+
+    OpenCL_SetupContext(globalVars, sampler)
+    OpenCL_InitializeMemory(globalVars)
+    OpenCL_RunKernel(globalVars, UpdateWindowFunc, numImagesToRender, &t1, &t2, &t3)
+
+``Backend`` exposes the same three steps with the same meaning and order
+(`setup_context`, `initialize_memory`, `run_kernel`) plus the range form the
+MI355X build adds (`render(first_iteration, n)`).  Python here is plumbing: every
+pixel is computed by the HIP kernels behind ``include/ptmi.h``; if the library or a
+GPU is missing the calls raise -- there is no CPU path in the product.
+
+Errors: the reference throws ``std::runtime_error`` for any backend failure
+(PathTracer_OpenCL.cpp:350-387,485); here every non-zero status raises ``PtmiError``
+(a RuntimeError) carrying ``ptmi_last_error``.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import structs as S
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libptmi.so")
+_lib = None
+
+
+class PtmiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"ptmi error {code}: {message}")
+        self.code = code
+
+
+class Float4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("image_width", C.c_uint32),
+                ("image_height", C.c_uint32), ("ray_max_depth", C.c_uint32), ("lights_size", C.c_uint32),
+                ("sampler", C.c_uint32), ("super_sampling", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32),
+                ("bvh", C.c_void_p), ("bvh_size", C.c_uint32),
+                ("triangulation", C.c_void_p), ("triangulation_size", C.c_uint32),
+                ("lights", C.c_void_p), ("lights_size", C.c_uint32),
+                ("materiaux", C.c_void_p), ("materiaux_size", C.c_uint32),
+                ("textures", C.c_void_p), ("textures_size", C.c_uint32),
+                ("textures_data", C.c_void_p), ("textures_data_size", C.c_uint32),
+                ("sky", C.c_void_p),
+                ("camera_position", Float4), ("camera_direction", Float4), ("camera_right", Float4),
+                ("camera_up", Float4)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "segments", "surface_hits", "shadow_rays", "box_tests",
+                                         "triangle_tests")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+FLAG_NO_HISTOGRAMS = 1
+
+# every symbol include/ptmi.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
+               "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_kernel_time",
+               "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_last_error",
+               "ptmi_abi_version", "ptmi_device_count", "ptmi_bvh_create"]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libptmi.so (built in-tree by ``__graft_entry__.build()`` / ``make lib``).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise PtmiError(-7, f"{_LIB_PATH} is missing: build it with `make lib` (there is no fallback path)")
+    lib = C.CDLL(_LIB_PATH)
+    vp, u32 = C.c_void_p, C.c_uint32
+    lib.ptmi_setup_context.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    lib.ptmi_initialize_memory.argtypes = [vp, C.POINTER(SceneDesc)]
+    lib.ptmi_render.argtypes = [vp, u32, u32]
+    lib.ptmi_synchronize.argtypes = [vp]
+    lib.ptmi_read_image.argtypes = [vp, vp, vp]
+    lib.ptmi_read_statistics.argtypes = [vp, vp, vp, vp]
+    lib.ptmi_clear.argtypes = [vp]
+    lib.ptmi_release.argtypes = [vp]
+    lib.ptmi_release.restype = None
+    lib.ptmi_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.ptmi_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
+    lib.ptmi_set_stream.argtypes = [vp, vp]
+    lib.ptmi_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.ptmi_bind_accumulators.argtypes = [vp, vp, vp]
+    lib.ptmi_last_error.argtypes = [vp]
+    lib.ptmi_last_error.restype = C.c_char_p
+    lib.ptmi_bvh_create.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def _f4(v):
+    v = np.asarray(v, np.float32)
+    return Float4(float(v[0]), float(v[1]), float(v[2]), float(v[3]))
+
+
+def bvh_create(scene):
+    """``BVH_Create(globalVars)`` (PathTracer_BVH.cpp:12-37): builds ``scene.bvh`` and reorders
+    ``scene.triangulation`` in place, exactly like the reference (host code, no GPU needed)."""
+    lib = load_library()
+    tris = np.ascontiguousarray(scene.triangulation)
+    if tris.dtype != S.Triangle:
+        raise PtmiError(-1, "triangulation must have the 336-byte structs.Triangle dtype")
+    n = len(tris)
+    nodes = np.zeros(max(2 * n - 1, 1), dtype=S.Node)
+    size, depth = C.c_uint32(0), C.c_uint32(0)
+    rc = lib.ptmi_bvh_create(_ptr(tris), n, _ptr(nodes), C.byref(size), C.byref(depth))
+    if rc:
+        raise PtmiError(rc, lib.ptmi_last_error(None).decode())
+    scene.triangulation = tris
+    scene.bvh = nodes[:size.value].copy()
+    scene.bvhMaxDepth = depth.value
+    return scene
+
+
+class Backend:
+    """One render context = the file-scope OpenCL objects of PathTracer_OpenCL.cpp:19-47."""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._ctx = C.c_void_p(None)
+        self.cfg = None
+        self._scene_keepalive = None
+
+    # -- error convention ---------------------------------------------------------------
+    def _check(self, rc):
+        if rc:
+            raise PtmiError(rc, self._lib.ptmi_last_error(self._ctx).decode())
+
+    # -- OpenCL_SetupContext(globalVars, sampler), OpenCL.cpp:316-402 ---------------------
+    def setup_context(self, image_width, image_height, ray_max_depth, lights_size, sampler=S.JITTERED,
+                      super_sampling=False, device=0, flags=0):
+        if self._ctx:
+            self.release()
+        cfg = Config(C.sizeof(Config), device, image_width, image_height, ray_max_depth, lights_size, sampler,
+                     1 if super_sampling else 0, flags)
+        ctx = C.c_void_p(None)
+        rc = self._lib.ptmi_setup_context(C.byref(ctx), C.byref(cfg))
+        if rc:
+            raise PtmiError(rc, self._lib.ptmi_last_error(None).decode())
+        self._ctx, self.cfg = ctx, cfg
+        return self
+
+    # -- OpenCL_InitializeMemory(globalVars), OpenCL.cpp:149-198 --------------------------
+    def initialize_memory(self, scene):
+        arrays = dict(bvh=np.ascontiguousarray(scene.bvh), tri=np.ascontiguousarray(scene.triangulation),
+                      lights=np.ascontiguousarray(scene.lights), mats=np.ascontiguousarray(scene.materiaux),
+                      tex=np.ascontiguousarray(scene.textures), texels=np.ascontiguousarray(scene.texturesData),
+                      sky=np.ascontiguousarray(scene.sky))
+        assert arrays["bvh"].dtype == S.Node and arrays["tri"].dtype == S.Triangle
+        d = SceneDesc()
+        d.struct_size = C.sizeof(SceneDesc)
+        d.bvh, d.bvh_size = _ptr(arrays["bvh"]), len(arrays["bvh"])
+        d.triangulation, d.triangulation_size = _ptr(arrays["tri"]), len(arrays["tri"])
+        d.lights, d.lights_size = _ptr(arrays["lights"]), len(arrays["lights"])
+        d.materiaux, d.materiaux_size = _ptr(arrays["mats"]), len(arrays["mats"])
+        d.textures, d.textures_size = _ptr(arrays["tex"]), len(arrays["tex"])
+        d.textures_data, d.textures_data_size = _ptr(arrays["texels"]), len(arrays["texels"])
+        d.sky = arrays["sky"].ctypes.data_as(C.c_void_p)
+        d.camera_position, d.camera_direction = _f4(scene.cameraPosition), _f4(scene.cameraDirection)
+        d.camera_right, d.camera_up = _f4(scene.cameraRight), _f4(scene.cameraUp)
+        self._check(self._lib.ptmi_initialize_memory(self._ctx, C.byref(d)))
+        return self
+
+    # -- one launch of the loop body of OpenCL_RunKernel, generalised to a range ----------
+    def render(self, first_iteration, n_iterations):
+        self._check(self._lib.ptmi_render(self._ctx, first_iteration, n_iterations))
+
+    def synchronize(self):
+        self._check(self._lib.ptmi_synchronize(self._ctx))
+
+    def clear(self):
+        self._check(self._lib.ptmi_clear(self._ctx))
+
+    def read_image(self):
+        """(imageColor float32[H,W,4], imageRayNb float32[H,W]) -- the per-image readback, OpenCL.cpp:97-98."""
+        h, w = self.cfg.image_height, self.cfg.image_width
+        color = np.empty((h, w, 4), np.float32)
+        count = np.empty((h, w), np.float32)
+        self._check(self._lib.ptmi_read_image(self._ctx, _ptr(color), _ptr(count)))
+        return color, count
+
+    def read_statistics(self):
+        """(rayDepths[D+1], rayIntersectedBBx[5000], rayIntersectedTri[5000]), OpenCL.cpp:110-112."""
+        d = np.zeros(self.cfg.ray_max_depth + 1, np.uint32)
+        b = np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32)
+        t = np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32)
+        self._check(self._lib.ptmi_read_statistics(self._ctx, _ptr(d), _ptr(b), _ptr(t)))
+        return d, b, t
+
+    def counters(self):
+        c = Counters()
+        self._check(self._lib.ptmi_get_counters(self._ctx, C.byref(c)))
+        return c.as_dict()
+
+    def kernel_time(self):
+        """(total_ms, launches) of the integrator kernel since the last call (HIP events on its stream)."""
+        ms, n = C.c_double(0), C.c_uint32(0)
+        self._check(self._lib.ptmi_kernel_time(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.ptmi_set_stream(self._ctx, C.c_void_p(hip_stream)))
+
+    def device_accumulators(self):
+        a, b = C.c_void_p(None), C.c_void_p(None)
+        self._check(self._lib.ptmi_device_accumulators(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def bind_accumulators(self, d_color, d_count):
+        self._check(self._lib.ptmi_bind_accumulators(self._ctx, C.c_void_p(d_color), C.c_void_p(d_count)))
+
+    # -- OpenCL_RunKernel(globalVars, UpdateWindowFunc, numImagesToRender, t1, t2, t3), OpenCL.cpp:56-140
+    def run_kernel(self, update_window_func=None, num_images_to_render=1, images_per_launch=1):
+        """The reference's render loop: launch, read the accumulators back, call the display callback,
+        once per image; statistics after the loop; then release.  Returns
+        (imageColor, imageRayNb, (rayDepths, bbx, tri), (pathTracingTime, memoryTime, displayTime)) with the
+        times in seconds.  ``images_per_launch`` > 1 batches iterations per launch (callback every batch)."""
+        t_path = t_mem = t_disp = 0.0
+        color = count = None
+        image_id = 0
+        while image_id < num_images_to_render:
+            n = min(images_per_launch, num_images_to_render - image_id)
+            t0 = time.perf_counter()
+            self.render(image_id, n)
+            self.synchronize()
+            t1 = time.perf_counter()
+            color, count = self.read_image()
+            t2 = time.perf_counter()
+            if update_window_func is not None:
+                update_window_func()  # return value ignored, as in OpenCL.cpp:103
+            t3 = time.perf_counter()
+            t_path += t1 - t0
+            t_mem += t2 - t1
+            t_disp += t3 - t2
+            image_id += n
+        stats = self.read_statistics()
+        self.release()
+        return color, count, stats, (t_path, t_mem, t_disp)
+
+    def release(self):
+        if self._ctx:
+            self._lib.ptmi_release(self._ctx)
+            self._ctx = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def render_scene(scene, width, height, ray_max_depth, n_iterations, first_iteration=0, sampler=S.JITTERED, device=0,
+                 flags=0):
+    """Convenience used by tests/bench: full life cycle for one iteration range."""
+    be = Backend().setup_context(width, height, ray_max_depth, scene.lightsSize, sampler, device=device, flags=flags)
+    try:
+        be.initialize_memory(scene)
+        be.render(first_iteration, n_iterations)
+        color, count = be.read_image()
+        stats = be.read_statistics()
+        counters = be.counters()
+    finally:
+        be.release()
+    return color, count, stats, counters

@@ -1,0 +1,502 @@
+// ptmi_api.cpp - host side of libptmi.so: the C ABI of include/ptmi.h.
+//
+// Mirrors the life cycle of the reference backend (Controleur/PathTracer_OpenCL.cpp):
+// setup_context -> initialize_memory -> render/read ... -> release, with the
+// differences DESIGN.md lists (accumulators are zeroed; a launch covers a range
+// of iterations; the scene is validated and re-laid out before upload).
+// No CPU fallback exists: without a HIP device nothing here computes.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ptmi.h"
+#include "ptmi_internal.h"
+
+using namespace ptmi_internal;
+
+namespace {
+std::mutex g_err_mutex;
+std::string g_err;  // failures that have no context yet
+}  // namespace
+
+void ptmi_internal::set_global_error(const std::string& msg)
+{
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    g_err = msg;
+}
+
+struct ptmi_ctx {
+    ptmi_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool have_scene = false;
+    std::string err;
+
+    // device memory owned by the context
+    std::vector<void*> allocations;
+    float* d_color = nullptr;
+    float* d_count = nullptr;
+    bool accum_bound = false;  // caller-owned accumulators
+    uint32_t* d_hist = nullptr;  // depths | bbx | tri
+    unsigned long long* d_counters = nullptr;
+    DScene ds{};
+
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    double kernel_ms = 0;
+    uint32_t kernel_launches = 0;
+};
+
+namespace {
+
+int fail(ptmi_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    else set_global_error(msg);
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                           \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return fail(ctx, PTMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+    } while (0)
+
+void free_scene_memory(ptmi_ctx* ctx)
+{
+    for (void* p : ctx->allocations) (void)hipFree(p);
+    ctx->allocations.clear();
+    ctx->d_color = ctx->d_count = nullptr;
+    ctx->d_hist = nullptr;
+    ctx->d_counters = nullptr;
+    ctx->accum_bound = false;
+    ctx->have_scene = false;
+}
+
+template <class T>
+int upload(ptmi_ctx* ctx, const std::vector<T>& host, const T** out)
+{
+    const size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);  // reference uploads >= 1 byte (OpenCL.cpp:165)
+    void* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, bytes));
+    ctx->allocations.push_back(d);
+    // blocking copy: the staging vectors are pageable and short-lived
+    if (!host.empty()) HIP_TRY(ctx, hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return PTMI_OK;
+}
+
+// Scene validation + re-layout.  Everything the kernel will index is checked
+// here so that a malformed scene is an error code, not a GPU fault.
+struct Relayout {
+    std::vector<DNode> nodes;
+    std::vector<DTri> tris;
+    std::vector<DShade> shade;
+    std::vector<DMat> mats;
+    std::vector<DBigLeaf> big_leaves;
+    uint32_t root_ref = 0;
+    uint32_t max_depth = 0;
+};
+
+bool texture_ok(const ptmi_texture& t, uint32_t data_size)
+{
+    if (t.width == 0 || t.height == 0) return false;
+    const uint64_t end = (uint64_t)t.offset + (uint64_t)t.width * t.height;
+    return end <= data_size;
+}
+
+int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
+{
+    const uint32_t nn = sc->bvh_size, nt = sc->triangulation_size;
+    if (nn == 0 || !sc->bvh) return fail(ctx, PTMI_ERR_BAD_SCENE, "bvh is empty (the kernel always reads bvh[0])");
+    if (nt && !sc->triangulation) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "triangulation is NULL");
+    if (nt > REF_INDEX_MASK_LEAF) return fail(ctx, PTMI_ERR_LIMIT, "more than 2^27 triangles");
+    if (sc->lights_size && !sc->lights) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "lights is NULL");
+    if (sc->materiaux_size && !sc->materiaux) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "materiaux is NULL");
+    if (!sc->sky) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "sky is NULL");
+    if (sc->textures_data_size && !sc->textures_data) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "textures_data is NULL");
+    if (sc->lights_size != ctx->cfg.lights_size)
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "scene.lights_size differs from config.lights_size (LIGHTS_SIZE is baked at setup)");
+
+    for (int f = 0; f < 6; f++)
+        if (!texture_ok(sc->sky->sky_textures[f], sc->textures_data_size))
+            return fail(ctx, PTMI_ERR_BAD_SCENE, "sky texture " + std::to_string(f) + " outside textures_data");
+    for (uint32_t i = 0; i < sc->textures_size; i++)
+        if (!texture_ok(sc->textures[i], sc->textures_data_size))
+            return fail(ctx, PTMI_ERR_BAD_SCENE, "texture " + std::to_string(i) + " outside textures_data");
+
+    out.mats.resize(sc->materiaux_size);
+    for (uint32_t i = 0; i < sc->materiaux_size; i++) {
+        const ptmi_material& m = sc->materiaux[i];
+        if (!m.is_simple_color && (m.texture_id < 0 || (uint32_t)m.texture_id >= sc->textures_size))
+            return fail(ctx, PTMI_ERR_BAD_SCENE, "material " + std::to_string(i) + " has an invalid textureId");
+        DMat& d = out.mats[i];
+        std::memcpy(d.color, &m.simple_color, 16);
+        d.opacity = m.opacity;
+        d.texture_id = m.texture_id;
+        d.type = m.type;
+        d.is_simple_color = m.is_simple_color ? 1u : 0u;
+    }
+
+    out.tris.resize(nt);
+    out.shade.resize(nt);
+    for (uint32_t i = 0; i < nt; i++) {
+        const ptmi_triangle& t = sc->triangulation[i];
+        if (t.mat_pos >= sc->materiaux_size || t.mat_neg >= sc->materiaux_size)
+            return fail(ctx, PTMI_ERR_BAD_SCENE, "triangle " + std::to_string(i) + " references a material out of range");
+        DTri& d = out.tris[i];
+        std::memcpy(d.s1, &t.s1, 16); std::memcpy(d.s2, &t.s2, 16); std::memcpy(d.s3, &t.s3, 16);
+        std::memcpy(d.n, &t.n, 16);
+        DShade& s = out.shade[i];
+        std::memset(&s, 0, sizeof s);
+        std::memcpy(s.n1, &t.n1, 16); std::memcpy(s.n2, &t.n2, 16); std::memcpy(s.n3, &t.n3, 16);
+        std::memcpy(s.uvp, &t.uvp1, 24);
+        std::memcpy(s.uvn, &t.uvn1, 24);
+        s.mat_pos = t.mat_pos;
+        s.mat_neg = t.mat_neg;
+    }
+
+    // Walk the tree from bvh[0] exactly as the traversal could, numbering inner
+    // nodes in pre-order.  `seen` rejects cycles and shared subtrees.
+    std::vector<uint8_t> seen(nn, 0);
+    auto make_ref = [&](uint32_t id, uint32_t* ref, std::string* why) -> bool {
+        if (id >= nn) { *why = "child index out of range"; return false; }
+        if (seen[id]) { *why = "node " + std::to_string(id) + " reached twice (cycle or shared subtree)"; return false; }
+        seen[id] = 1;
+        const ptmi_node& n = sc->bvh[id];
+        uint32_t r = n.triangles_aabb.is_empty ? REF_EMPTY : 0u;
+        if (n.is_leaf) {
+            if ((uint64_t)n.triangle_start_index + n.nb_triangles > nt) { *why = "leaf triangle range out of bounds"; return false; }
+            r |= REF_LEAF;
+            if (n.nb_triangles < REF_COUNT_BIG) {
+                r |= (n.nb_triangles << REF_COUNT_SHIFT) | n.triangle_start_index;
+            } else {
+                r |= (REF_COUNT_BIG << REF_COUNT_SHIFT) | (uint32_t)out.big_leaves.size();
+                out.big_leaves.push_back(DBigLeaf{n.triangle_start_index, n.nb_triangles});
+            }
+        } else {
+            if (n.cut_axis > 2) { *why = "cutAxis > 2"; return false; }
+            r |= (uint32_t)out.nodes.size();
+            out.nodes.emplace_back();
+        }
+        *ref = r;
+        return true;
+    };
+
+    std::string why;
+    if (!make_ref(0, &out.root_ref, &why)) return fail(ctx, PTMI_ERR_BAD_SCENE, "bvh[0]: " + why);
+    struct Item { uint32_t id, dnode, depth; };
+    std::vector<Item> todo;
+    if (!(out.root_ref & REF_LEAF)) todo.push_back({0, out.root_ref & REF_INDEX_MASK_INNER, 0});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        const ptmi_node& n = sc->bvh[it.id];
+        uint32_t r1, r2;
+        if (!make_ref(n.son1_id, &r1, &why) || !make_ref(n.son2_id, &r2, &why))
+            return fail(ctx, PTMI_ERR_BAD_SCENE, "bvh[" + std::to_string(it.id) + "]: " + why);
+        if (out.nodes.size() > REF_INDEX_MASK_INNER) return fail(ctx, PTMI_ERR_LIMIT, "too many bvh nodes");
+        DNode& d = out.nodes[it.dnode];
+        const ptmi_bounding_box& b1 = sc->bvh[n.son1_id].triangles_aabb;
+        const ptmi_bounding_box& b2 = sc->bvh[n.son2_id].triangles_aabb;
+        d.lo1[0] = b1.p_min.x; d.lo1[1] = b1.p_min.y; d.lo1[2] = b1.p_min.z;
+        d.hi1[0] = b1.p_max.x; d.hi1[1] = b1.p_max.y; d.hi1[2] = b1.p_max.z;
+        d.lo2[0] = b2.p_min.x; d.lo2[1] = b2.p_min.y; d.lo2[2] = b2.p_min.z;
+        d.hi2[0] = b2.p_max.x; d.hi2[1] = b2.p_max.y; d.hi2[2] = b2.p_max.z;
+        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.pad = 0;
+        const uint32_t child_depth = it.depth + 1;
+        if (child_depth > out.max_depth) out.max_depth = child_depth;
+        // push son2 first so son1's subtree is numbered right after its parent
+        if (!(r2 & REF_LEAF)) todo.push_back({n.son2_id, r2 & REF_INDEX_MASK_INNER, child_depth});
+        if (!(r1 & REF_LEAF)) todo.push_back({n.son1_id, r1 & REF_INDEX_MASK_INNER, child_depth});
+    }
+    // the traversal stack has 30 entries (FullKernel.cl:627); the reference refuses deeper trees (PathTracer.cpp:54-58)
+    if (out.max_depth >= PTMI_BVH_MAX_DEPTH)
+        return fail(ctx, PTMI_ERR_LIMIT, "bvh depth " + std::to_string(out.max_depth) + " >= 30");
+    return PTMI_OK;
+}
+
+int fold_events(ptmi_ctx* ctx)
+{
+    for (auto& ev : ctx->pending_events) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventSynchronize(ev.second));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        ctx->kernel_ms += ms;
+        ctx->kernel_launches++;
+        ctx->free_events.push_back(ev);
+    }
+    ctx->pending_events.clear();
+    return PTMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_abi_version(void) { return PTMI_ABI_VERSION; }
+
+int ptmi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* ptmi_last_error(const ptmi_ctx* ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_err;
+    return copy.c_str();
+}
+
+int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
+{
+    if (!out) return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "ctx out-pointer is NULL");
+    *out = nullptr;
+    if (!cfg || cfg->struct_size != sizeof(ptmi_config))
+        return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "config is NULL or struct_size mismatch (ABI)");
+    if (cfg->image_width == 0 || cfg->image_height == 0 || (uint64_t)cfg->image_width * cfg->image_height > 0x3FFFFFFFull)
+        return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "image size must be in [1, 2^30) pixels");
+    if (cfg->sampler > PTMI_SAMPLER_UNIFORM) return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "unknown sampler");
+    if (cfg->lights_size >= PTMI_MAX_LIGHT_SIZE)  // PathTracer.cpp:60-65
+        return fail(nullptr, PTMI_ERR_LIMIT, "lights_size >= 30");
+    if (cfg->super_sampling)
+        return fail(nullptr, PTMI_ERR_UNSUPPORTED, "SUPER_SAMPLING (adaptive sampling) is not built into this version");
+
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, PTMI_ERR_NO_DEVICE, "no HIP device available (there is no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= n) return fail(nullptr, PTMI_ERR_NO_DEVICE, "device ordinal out of range");
+
+    ptmi_ctx* ctx = new ptmi_ctx();
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("device/stream setup: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, PTMI_ERR_HIP, msg);
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PTMI_OK;
+}
+
+int ptmi_set_stream(ptmi_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = fold_events(ctx)) return rc;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PTMI_OK;
+}
+
+int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!sc || sc->struct_size != sizeof(ptmi_scene))
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "scene is NULL or struct_size mismatch (ABI)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene_memory(ctx);
+
+    Relayout lay;
+    if (int rc = build_layout(ctx, sc, lay)) return rc;
+
+    DScene& ds = ctx->ds;
+    ds = DScene{};
+    if (int rc = upload(ctx, lay.nodes, &ds.nodes)) return rc;
+    if (int rc = upload(ctx, lay.tris, &ds.tris)) return rc;
+    if (int rc = upload(ctx, lay.shade, &ds.shade)) return rc;
+    if (int rc = upload(ctx, lay.mats, &ds.mats)) return rc;
+    if (int rc = upload(ctx, lay.big_leaves, &ds.big_leaves)) return rc;
+    {
+        std::vector<ptmi_light> v(sc->lights, sc->lights + sc->lights_size);
+        if (int rc = upload(ctx, v, &ds.lights)) return rc;
+        std::vector<ptmi_texture> t(sc->textures, sc->textures + sc->textures_size);
+        if (int rc = upload(ctx, t, &ds.textures)) return rc;
+        std::vector<ptmi_uchar4> x(sc->textures_data, sc->textures_data + sc->textures_data_size);
+        if (int rc = upload(ctx, x, &ds.texels)) return rc;
+    }
+
+    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+    const size_t hist_words = (size_t)ctx->cfg.ray_max_depth + 1 + 2 * PTMI_MAX_INTERSECTION_NUMBER;
+    void *dc = nullptr, *dn = nullptr, *dh = nullptr, *dk = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dc, npix * 16)); ctx->allocations.push_back(dc);
+    HIP_TRY(ctx, hipMalloc(&dn, npix * 4));  ctx->allocations.push_back(dn);
+    HIP_TRY(ctx, hipMalloc(&dh, hist_words * 4)); ctx->allocations.push_back(dh);
+    HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8)); ctx->allocations.push_back(dk);
+    ctx->d_color = (float*)dc; ctx->d_count = (float*)dn; ctx->d_hist = (uint32_t*)dh;
+    ctx->d_counters = (unsigned long long*)dk;
+
+    ds.image_color = ctx->d_color;
+    ds.image_ray_nb = ctx->d_count;
+    const bool hist = !(ctx->cfg.flags & PTMI_FLAG_NO_HISTOGRAMS);
+    ds.hist_depths = hist ? ctx->d_hist : nullptr;
+    ds.hist_bbx = hist ? ctx->d_hist + ctx->cfg.ray_max_depth + 1 : nullptr;
+    ds.hist_tri = hist ? ctx->d_hist + ctx->cfg.ray_max_depth + 1 + PTMI_MAX_INTERSECTION_NUMBER : nullptr;
+    ds.counters = ctx->d_counters;
+    ds.sky = *sc->sky;
+    std::memcpy(ds.cam_pos, &sc->camera_position, 16);
+    std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
+    std::memcpy(ds.cam_right, &sc->camera_right, 16);
+    std::memcpy(ds.cam_up, &sc->camera_up, 16);
+    ds.root_ref = lay.root_ref;
+    ds.width = ctx->cfg.image_width;
+    ds.height = ctx->cfg.image_height;
+    ds.max_depth = ctx->cfg.ray_max_depth;
+    ds.n_lights = ctx->cfg.lights_size;
+    ds.sampler = ctx->cfg.sampler;
+
+    ctx->have_scene = true;
+    if (int rc = ptmi_clear(ctx)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+    return PTMI_OK;
+}
+
+int ptmi_clear(ptmi_ctx* ctx)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_clear before ptmi_initialize_memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+    const size_t hist_words = (size_t)ctx->cfg.ray_max_depth + 1 + 2 * PTMI_MAX_INTERSECTION_NUMBER;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_color, 0, npix * 16, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_ray_nb, 0, npix * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist, 0, hist_words * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * 8, ctx->stream));
+    return PTMI_OK;
+}
+
+int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_render before ptmi_initialize_memory");
+    if (n_iterations == 0) return PTMI_OK;
+    if ((uint64_t)first_iteration + n_iterations > 0xFFFFFFFFull)
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "iteration range overflows 32 bits");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending_events.size() >= 512)
+        if (int rc = fold_events(ctx)) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!ctx->free_events.empty()) {
+        ev = ctx->free_events.back();
+        ctx->free_events.pop_back();
+    } else {
+        HIP_TRY(ctx, hipEventCreate(&ev.first));
+        HIP_TRY(ctx, hipEventCreate(&ev.second));
+    }
+    HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
+    std::string err;
+    const int rc = launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err);
+    HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
+    ctx->pending_events.push_back(ev);
+    if (rc) return fail(ctx, rc, err);
+    return PTMI_OK;
+}
+
+int ptmi_synchronize(ptmi_ctx* ctx)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTMI_OK;
+}
+
+int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_image before ptmi_initialize_memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+    if (image_color) HIP_TRY(ctx, hipMemcpyAsync(image_color, ctx->ds.image_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (image_ray_nb) HIP_TRY(ctx, hipMemcpyAsync(image_ray_nb, ctx->ds.image_ray_nb, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTMI_OK;
+}
+
+int ptmi_read_statistics(ptmi_ctx* ctx, uint32_t* depths, uint32_t* bbx, uint32_t* tri)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_statistics before ptmi_initialize_memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t nd = ctx->cfg.ray_max_depth + 1;
+    if (depths) HIP_TRY(ctx, hipMemcpyAsync(depths, ctx->d_hist, nd * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bbx) HIP_TRY(ctx, hipMemcpyAsync(bbx, ctx->d_hist + nd, PTMI_MAX_INTERSECTION_NUMBER * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (tri) HIP_TRY(ctx, hipMemcpyAsync(tri, ctx->d_hist + nd + PTMI_MAX_INTERSECTION_NUMBER, PTMI_MAX_INTERSECTION_NUMBER * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTMI_OK;
+}
+
+int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out)
+{
+    if (!ctx || !out) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_get_counters before ptmi_initialize_memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[C_COUNT];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->paths = h[C_PATHS]; out->segments = h[C_SEGMENTS]; out->surface_hits = h[C_HITS];
+    out->shadow_rays = h[C_SHADOW]; out->box_tests = h[C_BBX]; out->triangle_tests = h[C_TRI];
+    return PTMI_OK;
+}
+
+int ptmi_kernel_time(ptmi_ctx* ctx, double* total_ms, uint32_t* n_launches)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = fold_events(ctx)) return rc;
+    if (total_ms) *total_ms = ctx->kernel_ms;
+    if (n_launches) *n_launches = ctx->kernel_launches;
+    ctx->kernel_ms = 0;
+    ctx->kernel_launches = 0;
+    return PTMI_OK;
+}
+
+int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_color, void** d_count)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_device_accumulators before ptmi_initialize_memory");
+    if (d_color) *d_color = ctx->ds.image_color;
+    if (d_count) *d_count = ctx->ds.image_ray_nb;
+    return PTMI_OK;
+}
+
+int ptmi_bind_accumulators(ptmi_ctx* ctx, void* d_color, void* d_count)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_bind_accumulators before ptmi_initialize_memory");
+    if ((d_color == nullptr) != (d_count == nullptr))
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "bind both accumulators or neither");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ds.image_color = d_color ? (float*)d_color : ctx->d_color;
+    ctx->ds.image_ray_nb = d_count ? (float*)d_count : ctx->d_count;
+    ctx->accum_bound = d_color != nullptr;
+    return PTMI_OK;
+}
+
+void ptmi_release(ptmi_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& ev : ctx->pending_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    free_scene_memory(ctx);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// ptmi_device.hpp - device-side building blocks of the integrator (gfx950).
+//
+// Numerics contract (DESIGN.md "Numerics"): every fp32 operation here is one
+// correctly rounded IEEE-754 +,-,*,/ or sqrt in a fixed association order,
+// compiled with -ffp-contract=off, so that a CPU evaluation of the same formulas
+// gives the same bits.  The formulas are those of the reference kernel; each
+// function cites the reference lines whose result it must reproduce.  OpenCL
+// float4 semantics apply: dot/length/normalize run over all FOUR components
+// (Appendix A.1 of SURVEY.md: the w lanes matter after a GLASS/WATER reflection).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ptmi_detmath.h"
+#include "ptmi_internal.h"
+
+namespace ptmi_dev {
+
+using namespace ptmi_internal;
+
+struct V4 {
+    float x, y, z, w;
+};
+
+__device__ __forceinline__ V4 v4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
+__device__ __forceinline__ V4 v4(const float* p) { return V4{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ V4 v4(const ptmi_float4& p) { return V4{p.x, p.y, p.z, p.w}; }
+__device__ __forceinline__ V4 v4(const float4& p) { return V4{p.x, p.y, p.z, p.w}; }
+__device__ __forceinline__ V4 operator+(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ V4 operator-(V4 a, V4 b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ V4 operator*(V4 a, V4 b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+__device__ __forceinline__ V4 operator*(V4 a, float s) { return V4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+__device__ __forceinline__ V4 operator/(V4 a, float s) { return V4{a.x / s, a.y / s, a.z / s, a.w / s}; }
+__device__ __forceinline__ V4 operator-(V4 a) { return V4{-a.x, -a.y, -a.z, -a.w}; }
+
+// OpenCL dot(float4,float4); association fixed as ((x+y)+z)+w
+__device__ __forceinline__ float dot(V4 a, V4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+__device__ __forceinline__ float length(V4 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V4 normalize(V4 a) { return a / length(a); }
+__device__ __forceinline__ V4 cross(V4 a, V4 b)
+{
+    return V4{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f};
+}
+
+constexpr float kPi = 3.14159265f;              // PATH_PI, header.cl:10
+constexpr float kPiInverse = 0.31830988618f;    // PATH_PI_INVERSE, header.cl:11
+constexpr float kMinContribution = 0.001f;      // MIN_CONTRIBUTION_VALUE, header.cl:15
+constexpr float kNWater = 1.333f, kNGlass = 1.55f, kNVarnish = 3.f, kSchlick = 0.8f;  // header.cl:166-169
+
+struct Ray {
+    V4 o, d;
+    float ix, iy, iz;  // inverse.xyz (inverse.w is never read)
+};
+
+// Ray3D_SetDirection, header.cl:276-284
+__device__ __forceinline__ void ray_set_direction(Ray& r, V4 d)
+{
+    r.d = normalize(d);
+    r.ix = 1.0f / r.d.x;
+    r.iy = 1.0f / r.d.y;
+    r.iz = 1.0f / r.d.z;
+}
+
+// random(), header.cl:246-253.  Only the low 31 bits of the 64-bit product
+// survive the mask, so a 32-bit multiply gives the same seed.
+__device__ __forceinline__ float lcg_random(int& seed)
+{
+    seed = (int)((16807u * (uint32_t)seed) & 0x7FFFFFFFu);
+    return (float)seed / 2147483648.0f;
+}
+
+// InitializeRandomSeed, header.cl:255-264 (all arithmetic is modulo 2^32)
+__device__ __forceinline__ int lcg_seed(uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration)
+{
+    uint32_t s = gx + gy * w + iteration * w * h;
+    s *= 2011u;
+    s *= s;
+    return (int)(s == 0u ? 1u : s);
+}
+
+// Vector_PutInSameHemisphereAs, header.cl:237-244
+__device__ __forceinline__ V4 put_in_same_hemisphere(V4 v, V4 n)
+{
+    const float d = dot(v, n);
+    if (d < 0.001f) v = v + n * (0.01f - d);
+    return v;
+}
+
+// BoundingBox_Intersects, FullKernel.cl:64-139, evaluated without branches.
+// Every comparison of the reference is kept with its operand order (NaNs from
+// 0*inf compare false exactly where they do there); the early returns become
+// one conjunction because the function has no side effects besides the counter,
+// which the caller bumps.
+__device__ __forceinline__ bool box_hit(const float lo[3], const float hi[3], bool is_empty, const Ray& r, float limit)
+{
+    const bool px = r.d.x > 0, py = r.d.y > 0, pz = r.d.z > 0;
+    float tmin = ((px ? lo[0] : hi[0]) - r.o.x) * r.ix;
+    float tmax = ((px ? hi[0] : lo[0]) - r.o.x) * r.ix;
+    bool ok = !(tmin < 0 && tmax < 0);
+    const float tymin = ((py ? lo[1] : hi[1]) - r.o.y) * r.iy;
+    const float tymax = ((py ? hi[1] : lo[1]) - r.o.y) * r.iy;
+    ok = ok && !(tymin < 0 && tymax < 0);
+    ok = ok && !(tmin > tymax || tymin > tmax);
+    tmin = tymin > tmin ? tymin : tmin;
+    tmax = tymax < tmax ? tymax : tmax;
+    const float tzmin = ((pz ? lo[2] : hi[2]) - r.o.z) * r.iz;
+    const float tzmax = ((pz ? hi[2] : lo[2]) - r.o.z) * r.iz;
+    ok = ok && !(tzmin < 0 && tzmax < 0);
+    ok = ok && !(tmin > tzmax || tzmin > tmax);
+    tmin = tzmin > tmin ? tzmin : tmin;
+    ok = ok && (tmin < 0 || !(tmin > limit));
+    return ok && !is_empty;
+}
+
+struct Hit {
+    V4 point;       // intersectionPoint
+    float s, t;
+    uint32_t tri;   // intersectedTriangleId
+    bool front;     // N.dir < 0  => materialWithPositiveNormalIndex (FullKernel.cl:568)
+};
+
+// Triangle_Intersects, FullKernel.cl:519-589, without the colour fetch (done
+// once for the final hit: the fetch is a pure function of triangle, side, s, t).
+__device__ __forceinline__ bool tri_hit(const DTri* __restrict__ tp, const Ray& r, float& limit, Hit& h)
+{
+    const float4* q4 = reinterpret_cast<const float4*>(tp);
+    const V4 S1 = v4(q4[0]), S2 = v4(q4[1]), S3 = v4(q4[2]), N = v4(q4[3]);
+    const V4 u = S2 - S1;
+    const V4 v = S3 - S1;
+    const float d = dot(N, S1);
+    const float nd = dot(N, r.d);
+    if ((nd > -0.00001f) && (nd < 0.00001f)) return false;
+    const V4 q = r.o + (r.d * ((d - dot(N, r.o)) / nd));
+    const V4 full = q - r.o;
+    const float nsd = dot(full, full);
+    if (nsd > limit) return false;
+    if (nsd < 0.00001f) return false;
+    const V4 w = q - S1;
+    const float uv = dot(u, v), wv = dot(w, v), wu = dot(w, u), uu = dot(u, u), vv = dot(v, v);
+    const float denom = 1 / (uv * uv - uu * vv);
+    const float s = (uv * wv - vv * wu) * denom;
+    const float t = (uv * wu - uu * wv) * denom;
+    if (s < 0 || t < 0 || s + t > 1) return false;
+    if (dot(full, r.d) < 0) return false;
+    limit = nsd;
+    h.point = q;
+    h.s = s;
+    h.t = t;
+    h.front = nd < 0;
+    return true;
+}
+
+// Texture_GetPixelColorValue, header.cl:430-459
+__device__ __forceinline__ V4 texture_pixel(const ptmi_texture& tex, const ptmi_uchar4* __restrict__ texels, float u, float v)
+{
+    u = u - (float)((int)u) + (float)(u < 0 ? 1 : 0);
+    v = v - (float)((int)v) + (float)(v < 0 ? 1 : 0);
+    const uint32_t x = (uint32_t)(u * (float)(tex.width - 1u));
+    const uint32_t y = (uint32_t)(v * (float)(tex.height - 1u));
+    const ptmi_uchar4 p = texels[tex.offset + y * tex.width + x];
+    V4 c = V4{(float)p.x / 255.f, (float)p.y / 255.f, (float)p.z / 255.f, (float)p.w / 255.f};
+    c.w = 1.f - c.w;
+    return c;
+}
+
+// Sky_GetColorValue + Sky_GetFaceColorValue, FullKernel.cl:438-512
+__device__ __forceinline__ V4 sky_color(const ptmi_sky& sky, const ptmi_uchar4* __restrict__ texels, V4 d)
+{
+    const float x = sky.cos_rotation_angle * d.x - sky.sin_rotation_angle * d.y;
+    const float y = sky.sin_rotation_angle * d.x + sky.cos_rotation_angle * d.y;
+    const float z = d.z;
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    int face = 0;
+    float u = 0, v = 0;
+    if (az > ax && az > ay) {
+        if (z > 0) { face = 5; u = (1 - x / z) / 2; v = (1 + y / z) / 2; }
+        else       { face = 0; u = (1 + x / z) / 2; v = (1 + y / z) / 2; }
+    } else if (ax > ay && ax > az) {
+        if (x > 0) { face = 1; u = (1 - y / x) / 2; v = (1 + z / x) / 2; }
+        else       { face = 3; u = (1 - y / x) / 2; v = (1 - z / x) / 2; }
+    } else if (ay > ax && ay > az) {
+        if (y > 0) { face = 4; u = (1 + x / y) / 2; v = (1 + z / y) / 2; }
+        else       { face = 2; u = (1 + x / y) / 2; v = (1 - z / y) / 2; }
+    }
+    return texture_pixel(sky.sky_textures[face], texels, u, v);
+}
+
+// Fresnel core shared by FullKernel.cl:192-217 (glass), :219-254 (water), :256-292 (varnish)
+__device__ __forceinline__ float fresnel_fraction(float n1, float n2, float cos1, V4 incident, V4 N, V4* refr)
+{
+    const float sin1 = sqrtf(1 - cos1 * cos1);
+    const float sin2 = n1 * sin1 / n2;
+    if (sin2 >= 1) return 1;
+    const float cos2 = sqrtf(1 - sin2 * sin2);
+    const float r_para = (n2 * cos1 - n1 * cos2) / (n2 * cos1 + n1 * cos2);
+    const float r_perp = (n1 * cos1 - n2 * cos2) / (n1 * cos1 + n2 * cos2);
+    if (refr) *refr = incident * (n1 / n2) + N * (n1 / n2 * cos1 - cos2);
+    return (r_para * r_para + r_perp * r_perp) / 2.0f;
+}
+
+__device__ __forceinline__ float fresnel_varnish(V4 incident, V4 N)
+{
+    const float cos1 = fmaxf(0.f, fminf(1.f, -dot(incident, N)));
+    return fresnel_fraction(1.0f, kNVarnish, cos1, incident, N, nullptr);
+}
+
+// Material_FresnelReflection, FullKernel.cl:294-300
+__device__ __forceinline__ V4 reflect_about(V4 v, V4 N) { return v - (N * (2 * dot(v, N))); }
+
+// Material_BRDF, FullKernel.cl:166-190
+__device__ __forceinline__ float material_brdf(int type, V4 incident, V4 N, V4 reflected)
+{
+    if (type == PTMI_MAT_STANDART) return kPiInverse;
+    if (type == PTMI_MAT_GLASS) return 1;
+    if (type == PTMI_MAT_WATER) {
+        const float denom = 1 + kSchlick * dot(incident, reflected);
+        return (1 - kSchlick * kSchlick) / (4 * kPi * denom * denom);
+    }
+    if (type == PTMI_MAT_VARNHISHED) return (1 - fresnel_varnish(incident, N)) * kPiInverse;
+    return 1;
+}
+
+// Material_ConcentricSampleDisk (FullKernel.cl:339-416) + Material_CosineSampleHemisphere (:303-336)
+__device__ __forceinline__ V4 cosine_sample_hemisphere(int& seed, V4 N)
+{
+    const float u1 = lcg_random(seed);
+    const float u2 = lcg_random(seed);
+    const float sx = 2 * u1 - 1;
+    const float sy = 2 * u2 - 1;
+    float r, theta;
+    if (fabsf(sx) < 0.0001f) { r = sy; theta = 0; }
+    else if (fabsf(sy) < 0.0001f) { r = sx; theta = 2; }
+    else if (sx > -sy) {
+        if (sx > sy) { r = sx; theta = sy > 0 ? sy / sx : 8.f + sy / sx; }
+        else { r = sy; theta = 2.f - sx / sy; }
+    } else {
+        if (sx < sy) { r = -sx; theta = 4.f + sy / sx; }
+        else { r = -sy; theta = 6.f - sy / sx; }
+    }
+    theta *= kPi / 4.f;
+    r = (float)((double)r * 0.999);  // FullKernel.cl:408: the literal is a double
+    float sn, cs;
+    ptmi_sincosf(theta, &sn, &cs);
+    const float x = r * cs, y = r * sn;
+    float z = 1 - x * x - y * y;
+    z = (z < 0) ? 0 : sqrtf(z);
+    const V4 v = v4(x, y, z, 0);
+    if (N.z > 0.9999f) return v;
+    if (N.z < -0.9999f) return -v;
+    const V4 sn4 = normalize(v4(-N.y, N.x, 0, 0));
+    const V4 tn4 = normalize(cross(N, sn4));
+    return normalize(v4(dot(v4(sn4.x, tn4.x, N.x, 0), v), dot(v4(sn4.y, tn4.y, N.y, 0), v),
+                        dot(v4(sn4.z, tn4.z, N.z, 0), v), 0));
+}
+
+// Light_PowerToward, header.cl:403-421
+__device__ __forceinline__ float light_power_toward(const ptmi_light& l, V4 p, V4 N)
+{
+    const V4 pos = v4(l.position), dir = v4(l.direction);
+    if (l.type == PTMI_LIGHT_DIRECTIONNAL) return l.power * fmaxf(dot(-dir, N), 0.f);
+    if (l.type == PTMI_LIGHT_POINT) {
+        const V4 d = p - pos;
+        return l.power / dot(d, d) * fmaxf(dot(normalize(pos - p), N), 0.f);
+    }
+    if (l.type == PTMI_LIGHT_SPOT) {
+        const V4 lrd = normalize(p - pos);
+        const float cos_angle = dot(lrd, dir);
+        if (cos_angle > l.cos_inner) return l.power * fmaxf(-dot(lrd, N), 0.f);
+        if (cos_angle < l.cos_outer) return 0.0f;
+        return l.power * (cos_angle - l.cos_outer) / (l.cos_inner - l.cos_outer) * fmaxf(-dot(lrd, N), 0.f);
+    }
+    return 0.f;
+}
+
+}  // namespace ptmi_dev

@@ -1,0 +1,107 @@
+// ptmi_internal.h - shared between the host side of libptmi.so and its HIP kernels.
+// Not part of the ABI.
+#pragma once
+
+#include <cstdint>
+#include <string>
+
+#include "ptmi.h"
+
+namespace ptmi_internal {
+
+void set_global_error(const std::string& msg);
+
+// ---- device-side scene layout (see DESIGN.md "Data layout in HBM") ----------
+//
+// The reference walks 160-byte Node records and copies 336-byte Triangles into
+// private memory for every test (FullKernel.cl:640,671-672).  At upload the
+// scene is re-laid out so that one traversal step touches one aligned 64-byte
+// record and nothing it does not need:
+//
+//  DNode (64 B, one per INNER node): both children's boxes + child references.
+//  DTri  (64 B, one per triangle, BVH order): S1,S2,S3,N as stored (xyzw).
+//  DShade (112 B, one per triangle): what only a confirmed surface hit reads.
+//  DMat  (32 B): material without the host pointer.
+//
+// A child reference ("ref") packs what the traversal needs to know about the
+// child without touching it:
+//   bit 31      : child is a leaf
+//   bit 30      : child's trianglesAABB.isEmpty (box test returns false, FullKernel.cl:68)
+//   inner child : bits 29..0 = index into DNode[]
+//   leaf child  : bits 29..27 = triangle count 0..6, or 7 = "big leaf";
+//                 bits 26..0  = first triangle (count<=6) or index into big_leaves[]
+constexpr uint32_t REF_LEAF = 0x80000000u;
+constexpr uint32_t REF_EMPTY = 0x40000000u;
+constexpr uint32_t REF_COUNT_SHIFT = 27;
+constexpr uint32_t REF_COUNT_BIG = 7;
+constexpr uint32_t REF_INDEX_MASK_INNER = 0x3FFFFFFFu;
+constexpr uint32_t REF_INDEX_MASK_LEAF = 0x07FFFFFFu;
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // traversal finished (never a valid ref: leaf+empty+count 7 + all ones)
+
+struct DNode {
+    float lo1[3], hi1[3];  // son1Id's trianglesAABB pMin/pMax xyz
+    float lo2[3], hi2[3];  // son2Id's
+    uint32_t ref1, ref2;
+    uint32_t axis;  // cutAxis
+    uint32_t pad;
+};
+static_assert(sizeof(DNode) == 64, "DNode");
+
+struct DTri {
+    float s1[4], s2[4], s3[4], n[4];
+};
+static_assert(sizeof(DTri) == 64, "DTri");
+
+struct DShade {
+    float n1[4], n2[4], n3[4];
+    float uvp[6];  // UVP1.xy UVP2.xy UVP3.xy
+    float uvn[6];
+    uint32_t mat_pos, mat_neg;
+    uint32_t pad[2];
+};
+static_assert(sizeof(DShade) == 112, "DShade");
+
+struct DMat {
+    float color[4];
+    float opacity;
+    int32_t texture_id;
+    int32_t type;
+    uint32_t is_simple_color;
+};
+static_assert(sizeof(DMat) == 32, "DMat");
+
+struct DBigLeaf {
+    uint32_t start, count;
+};
+
+enum CounterSlot { C_PATHS = 0, C_SEGMENTS, C_HITS, C_SHADOW, C_BBX, C_TRI, C_COUNT };
+
+// Everything a launch needs, passed by value (lives in SGPRs / kernarg).
+struct DScene {
+    const DNode* nodes;
+    const DTri* tris;
+    const DShade* shade;
+    const DMat* mats;
+    const ptmi_light* lights;
+    const ptmi_texture* textures;
+    const ptmi_uchar4* texels;
+    const DBigLeaf* big_leaves;
+    float* image_color;   // float4[W*H]
+    float* image_ray_nb;  // float[W*H]
+    uint32_t* hist_depths;  // [D+1]   (nullptr = histograms off)
+    uint32_t* hist_bbx;     // [5000]
+    uint32_t* hist_tri;     // [5000]
+    unsigned long long* counters;  // [C_COUNT]
+    ptmi_sky sky;
+    float cam_pos[4], cam_dir[4], cam_right[4], cam_up[4];
+    uint32_t root_ref;
+    uint32_t width, height;
+    uint32_t max_depth;  // MAX_REFLECTION_NUMBER
+    uint32_t n_lights;   // LIGHTS_SIZE
+    uint32_t sampler;
+};
+
+// kernels.hip
+int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, void* stream, std::string* err);
+
+}  // namespace ptmi_internal

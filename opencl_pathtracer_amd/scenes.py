@@ -1,0 +1,424 @@
+"""Scene construction for the integrator: the conventions the reference's importers follow.
+
+The reference ships no scene assets and its only live importer needs the Maya SDK
+(``Maya/PathTracer_MayaImporter.cpp``).  What that importer *does* to raw geometry is
+the de-facto spec of valid scene data, so it is restated here with numpy (vectorised,
+float32, one rounding per operation like the host code):
+
+* ``triangle_create``  <- ``Triangle_Create`` (MayaImporter.cpp:943-1047): AABB, geometric normal
+  from the ORIGINAL winding with ``w = 1`` (host ``cross`` returns w=1, Utils.h:131), vertices
+  sorted lexicographically together with their attributes, vertex normals normalised or replaced
+  by ``N`` when degenerate.
+* points carry ``w = 1``, directions ``w = 0`` (MayaImporter.h:29-37).
+* lights / materials / "no sky"  <- MayaImporter.cpp:819-850, 852-932, 695-719.
+
+The generators below build the BASELINE.json workloads (Cornell box, N random triangles)
+and a material/texture/light mix used by the parity tests.  Every scene is a ``Scene``:
+the subset of the reference's ``GlobalVars`` (PathTracer_Structs.h:145-189) the device
+backend reads.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import structs as S
+
+f32 = np.float32
+
+
+@dataclass
+class Scene:
+    triangulation: np.ndarray
+    lights: np.ndarray
+    materiaux: np.ndarray
+    textures: np.ndarray
+    texturesData: np.ndarray
+    sky: np.ndarray
+    cameraPosition: np.ndarray
+    cameraDirection: np.ndarray
+    cameraRight: np.ndarray
+    cameraUp: np.ndarray
+    bvh: np.ndarray = None
+    bvhMaxDepth: int = 0
+    name: str = ""
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def lightsSize(self):
+        return len(self.lights)
+
+
+# --------------------------------------------------------------------------- helpers
+
+def _f4(xyz, w):
+    xyz = np.asarray(xyz, dtype=f32)
+    out = np.empty(xyz.shape[:-1] + (4,), dtype=f32)
+    out[..., :3] = xyz
+    out[..., 3] = w
+    return out
+
+
+def _dot3(a, b):
+    # host dot(), Utils.h:130: (x*x) + (y*y) + (z*z), float
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def _cross3(a, b):
+    # host cross(), Utils.h:131 (w handled by the caller)
+    return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1],
+                     a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                     a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], axis=-1).astype(f32)
+
+
+def triangle_create(s1, s2, s3, normals=None, uvp=None, uvn=None, mat_pos=0, mat_neg=None, first_id=0):
+    """Vectorised ``Triangle_Create`` (MayaImporter.cpp:943-1047).
+
+    s1,s2,s3: (n,3) vertex positions in the caller's winding.  normals: (n,3,3) per-vertex
+    normals (zero rows trigger the reference's fallback to N, which carries w=1) or None for
+    flat shading with proper w=0 normals.  uvp/uvn: (n,3,2).  Returns a Triangle array.
+    """
+    s = np.stack([np.asarray(s1, f32), np.asarray(s2, f32), np.asarray(s3, f32)], axis=1)  # (n,3,3)
+    n = s.shape[0]
+    tri = np.zeros(n, dtype=S.Triangle)
+
+    p = _f4(s, 1.0)  # points: w = 1
+    # BoundingBox_Create, Structs.h:197-205 (all four components)
+    pmin = np.minimum(np.minimum(p[:, 0], p[:, 1]), p[:, 2])
+    pmax = np.maximum(np.maximum(p[:, 0], p[:, 1]), p[:, 2])
+    tri["AABB"]["pMin"] = pmin
+    tri["AABB"]["pMax"] = pmax
+    tri["AABB"]["centroid"] = (pmin + pmax) / f32(2)
+    tri["AABB"]["isEmpty"] = 0
+
+    # N = normalize(cross(s2-s1, s3-s1)) with the ORIGINAL order; host normalize keeps w (=1)
+    c = _cross3(s[:, 1] - s[:, 0], s[:, 2] - s[:, 0])
+    length = np.sqrt(_dot3(c, c)).astype(f32)
+    N = _f4(c / length[:, None], 1.0)
+    tri["N"] = N
+
+    if normals is None:
+        nrm = np.repeat(N[:, None, :3], 3, axis=1)
+    else:
+        nrm = np.asarray(normals, f32)
+    nrm4 = _f4(nrm, 0.0)  # directions: w = 0
+    uvp = np.zeros((n, 3, 2), f32) if uvp is None else np.asarray(uvp, f32)
+    uvn = uvp if uvn is None else np.asarray(uvn, f32)
+
+    # lexicographic vertex order (Vector_LexLessThan cascade, :964-1017) == a sort on (x,y,z)
+    order = np.lexsort((s[:, :, 2], s[:, :, 1], s[:, :, 0]), axis=1)
+    rows = np.arange(n)[:, None]
+    p = p[rows, order]
+    nrm4 = nrm4[rows, order]
+    uvp = uvp[rows, order]
+    uvn = uvn[rows, order]
+
+    # vertex normals: length < 0.5 -> N (w=1!), else divide all four components (:1028-1033)
+    ln = np.sqrt(_dot3(nrm4, nrm4)).astype(f32)
+    bad = ln < f32(0.5)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nn = nrm4 / ln[..., None]
+    nn = np.where(bad[..., None], N[:, None, :], nn).astype(f32)
+
+    for k, name in enumerate(("S1", "S2", "S3")):
+        tri[name] = p[:, k]
+    for k, name in enumerate(("N1", "N2", "N3")):
+        tri[name] = nn[:, k]
+    for k, name in enumerate(("UVP1", "UVP2", "UVP3")):
+        tri[name] = uvp[:, k]
+    for k, name in enumerate(("UVN1", "UVN2", "UVN3")):
+        tri[name] = uvn[:, k]
+    tri["materialWithPositiveNormalIndex"] = mat_pos
+    tri["materialWithNegativeNormalIndex"] = mat_pos if mat_neg is None else mat_neg
+    tri["id"] = np.arange(first_id, first_id + n, dtype=np.uint32)
+    return tri
+
+
+def material_create(mtype=S.MAT_STANDART, color=(0.5, 0.5, 0.5, 0.0), texture_id=-1, opacity=1.0):
+    """Material_Create overloads (MayaImporter.cpp:852-932): textured iff textureId >= 0."""
+    m = np.zeros((), dtype=S.Material)
+    m["type"] = mtype
+    m["simpleColor"] = np.asarray(color, f32)
+    m["textureId"] = texture_id if texture_id >= 0 else 0
+    m["isSimpleColor"] = 1 if texture_id < 0 else 0
+    m["hasAlphaMap"] = 0
+    m["opacity"] = opacity
+    return m
+
+
+def light_point(position, color=(1, 1, 1, 1), power=1.0):
+    l = np.zeros((), dtype=S.Light)  # Light_Create(MFnPointLight), MayaImporter.cpp:819-828
+    l["type"] = S.LIGHT_POINT
+    l["color"] = np.asarray(color, f32)
+    l["direction"] = (0, 0, 0, 1)
+    l["position"] = _f4(position, 1.0)
+    l["power"] = power
+    return l
+
+
+def light_directional(direction, color=(1, 1, 1, 1), power=1.0):
+    l = np.zeros((), dtype=S.Light)  # MayaImporter.cpp:830-839
+    d = np.asarray(direction, f32)
+    d = d / np.sqrt(_dot3(d, d)).astype(f32)
+    l["type"] = S.LIGHT_DIRECTIONNAL
+    l["color"] = np.asarray(color, f32)
+    l["direction"] = _f4(d, 0.0)
+    l["position"] = (0, 0, 0, 1)
+    l["power"] = power
+    return l
+
+
+def light_spot(position, direction, cone_angle, penumbra_angle, color=(1, 1, 1, 1), intensity=1.0):
+    l = np.zeros((), dtype=S.Light)  # MayaImporter.cpp:841-850
+    d = np.asarray(direction, f32)
+    d = d / np.sqrt(_dot3(d, d)).astype(f32)
+    l["type"] = S.LIGHT_SPOT
+    l["color"] = np.asarray(color, f32)
+    l["cosOfInnerFallOffAngle"] = f32(np.cos(cone_angle / 2))
+    l["cosOfOuterFallOffAngle"] = f32(np.cos(cone_angle / 2 + penumbra_angle))
+    l["direction"] = _f4(d, 0.0)
+    l["position"] = _f4(position, 1.0)
+    l["power"] = 3 * intensity
+    return l
+
+
+def no_sky(rgba=(0, 0, 0, 0)):
+    """LoadSkyAndAllocateTextureMemory(loadSky=false), MayaImporter.cpp:695-719: six 1x1 faces at texel 0."""
+    sky = np.zeros((), dtype=S.Sky)
+    sky["cosRotationAngle"] = 1
+    sky["sinRotationAngle"] = 0
+    sky["groundScale"] = 1
+    for i in range(6):
+        sky["skyTextures"][i] = (1, 1, 0)
+    texels = np.array([rgba], dtype=np.uint8)
+    return sky, texels
+
+
+def camera(position, direction, right, up):
+    return _f4(position, 1.0), _f4(direction, 0.0), _f4(right, 0.0), _f4(up, 0.0)
+
+
+def _quad(a, b, c, d):
+    """two triangles a-b-c, a-c-d"""
+    a, b, c, d = (np.asarray(v, f32) for v in (a, b, c, d))
+    return np.array([a, a]), np.array([b, c]), np.array([c, d])
+
+
+def _concat_tris(parts):
+    # not np.concatenate: numpy "promotes" padded struct dtypes to a packed layout
+    t = np.zeros(sum(len(p) for p in parts), dtype=S.Triangle)
+    k = 0
+    for p in parts:
+        assert p.dtype == S.Triangle
+        t[k:k + len(p)] = p
+        k += len(p)
+    t["id"] = np.arange(len(t), dtype=np.uint32)
+    return t
+
+
+# --------------------------------------------------------------------------- BASELINE workloads
+
+def cornell_box(width, height):
+    """BASELINE configs 1-2: Cornell box, 32 triangles, one point light under a (non-emissive) lamp quad.
+
+    555-unit scale, z up.  The reference has no emissive materials: light comes from Light[] and sky only.
+    """
+    WHITE, RED, GREEN = 0, 1, 2
+    mats = np.array([material_create(color=(0.73, 0.73, 0.73, 0)), material_create(color=(0.65, 0.05, 0.05, 0)),
+                     material_create(color=(0.12, 0.45, 0.15, 0))], dtype=S.Material)
+    parts = []
+
+    def add_quad(a, b, c, d, mat):
+        s1, s2, s3 = _quad(a, b, c, d)
+        parts.append(triangle_create(s1, s2, s3, mat_pos=mat))
+
+    L = 555.0
+    add_quad((0, 0, 0), (L, 0, 0), (L, L, 0), (0, L, 0), WHITE)          # floor
+    add_quad((0, 0, L), (0, L, L), (L, L, L), (L, 0, L), WHITE)          # ceiling
+    add_quad((0, L, 0), (L, L, 0), (L, L, L), (0, L, L), WHITE)          # back wall
+    add_quad((0, 0, 0), (0, L, 0), (0, L, L), (0, 0, L), RED)            # left wall
+    add_quad((L, 0, 0), (L, 0, L), (L, L, L), (L, L, 0), GREEN)          # right wall
+
+    def add_block(corners, h):
+        c = [np.array([x, y, 0.0], f32) for x, y in corners]
+        t = [v + np.array([0, 0, h], f32) for v in c]
+        add_quad(t[0], t[1], t[2], t[3], WHITE)                           # top
+        for i in range(4):
+            j = (i + 1) % 4
+            add_quad(c[i], c[j], t[j], t[i], WHITE)                       # sides
+
+    add_block([(130, 65), (82, 225), (240, 272), (290, 114)], 165.0)      # short block
+    add_block([(423, 247), (265, 296), (314, 456), (472, 406)], 330.0)    # tall block
+    add_quad((213, 227, 554.9), (343, 227, 554.9), (343, 332, 554.9), (213, 332, 554.9), WHITE)  # lamp quad
+
+    tris = _concat_tris(parts)
+    assert len(tris) == 32
+    lights = np.array([light_point((278.0, 279.5, 540.0), power=250000.0)], dtype=S.Light)
+    sky, texels = no_sky()
+    span = 0.75
+    pos, d, r, u = camera((278.0, -800.0, 273.0), (0, 1, 0), (span, 0, 0), (0, 0, span * height / width))
+    return Scene(tris, lights, mats, np.zeros(0, S.Texture), texels, sky, pos, d, r, u, name="cornell")
+
+
+def random_triangles(n, width, height, seed=12345):
+    """BASELINE config 3: n random triangles, centres U[-5,5]^3, vertices centre + U[-0.1,0.1]^3.
+
+    Generator pinned here: numpy MT19937 ``RandomState(seed)``; first ``uniform(-5,5,(n,3))`` for
+    the centres, then ``uniform(-0.1,0.1,(n,3,3))`` for the vertex offsets (vertex-major), both
+    rounded to float32 before the add.
+    """
+    rs = np.random.RandomState(seed)
+    centres = rs.uniform(-5.0, 5.0, (n, 3)).astype(f32)
+    offs = rs.uniform(-0.1, 0.1, (n, 3, 3)).astype(f32)
+    v = (centres[:, None, :] + offs).astype(f32)
+    tris = triangle_create(v[:, 0], v[:, 1], v[:, 2], mat_pos=0)
+    mats = np.array([material_create(color=(0.7, 0.7, 0.7, 0))], dtype=S.Material)
+    lights = np.array([light_point((-9.0, 3.0, 6.0), power=60.0)], dtype=S.Light)
+    sky, texels = no_sky((200, 200, 200, 255))
+    pos, d, r, u = camera((-14.0, 0.0, 0.0), (1, 0, 0), (0, 1, 0), (0, 0, height / width))
+    return Scene(tris, lights, mats, np.zeros(0, S.Texture), texels, sky, pos, d, r, u, name=f"tris{n}",
+                 meta={"seed": seed})
+
+
+# --------------------------------------------------------------------------- parity-test mix
+
+def _icosphere(subdiv):
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v), np.array(f)
+
+
+def _sphere_tris(center, radius, subdiv, mat_pos, mat_neg=None, smooth=True):
+    v, f = _icosphere(subdiv)
+    p = (v * radius + np.asarray(center)).astype(f32)
+    nrm = v.astype(f32)
+    s = p[f]  # (n,3,3)
+    normals = nrm[f] if smooth else None
+    # spherical uv
+    uv = np.stack([np.arctan2(v[:, 1], v[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(v[:, 2], -1, 1)) / np.pi],
+                  axis=-1).astype(f32)
+    return triangle_create(s[:, 0], s[:, 1], s[:, 2], normals=normals, uvp=uv[f], uvn=(uv[f] * f32(3.0)).astype(f32),
+                           mat_pos=mat_pos, mat_neg=mat_neg)
+
+
+def _checker(w, h, c0, c1, cell=4):
+    yy, xx = np.mgrid[0:h, 0:w]
+    m = ((xx // cell + yy // cell) % 2).astype(bool)
+    t = np.where(m[..., None], np.array(c1, np.uint8), np.array(c0, np.uint8)).astype(np.uint8)
+    return t.reshape(-1, 4)
+
+
+def _gradient(w, h, rgb0, rgb1):
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = ((xx + yy) / float(w + h - 2))[..., None]
+    t = np.concatenate([(1 - a) * np.array(rgb0) + a * np.array(rgb1), np.full((h, w, 1), 255.0)], axis=-1)
+    return np.clip(t, 0, 255).astype(np.uint8).reshape(-1, 4)
+
+
+def material_mix(width, height):
+    """Parity-test scene touching every branch the kernel has: all five material types, textured and
+    two-sided materials, smooth and fallback (w=1) vertex normals, point + spot + directional lights,
+    a six-face cubemap sky.  Not a BASELINE workload."""
+    texels = []
+    textures = []
+
+    def add_tex(img, w, h):
+        off = sum(len(t) for t in texels)
+        texels.append(img)
+        textures.append((w, h, off))
+        return len(textures) - 1
+
+    sky = np.zeros((), dtype=S.Sky)
+    sky["cosRotationAngle"] = f32(np.cos(0.3))
+    sky["sinRotationAngle"] = f32(np.sin(0.3))
+    sky["groundScale"] = 1
+    face_cols = [((40, 40, 60), (90, 90, 140)), ((200, 120, 60), (250, 220, 160)), ((60, 140, 200), (160, 220, 250)),
+                 ((120, 200, 120), (220, 250, 220)), ((200, 200, 80), (250, 250, 200)), ((120, 160, 250), (230, 240, 255))]
+    for i, (c0, c1) in enumerate(face_cols):
+        off = sum(len(t) for t in texels)
+        texels.append(_gradient(16, 16, c0, c1))
+        sky["skyTextures"][i] = (16, 16, off)
+
+    t_check = add_tex(_checker(32, 32, (230, 230, 230, 0), (40, 40, 160, 0)), 32, 32)
+    t_wood = add_tex(_gradient(24, 8, (150, 90, 40), (220, 170, 90)), 24, 8)
+
+    M = dict(floor=0, red=1, glass=2, water=3, varnish_tex=4, metal=5, varnish=6, blue=7, white=8)
+    mats = np.array([
+        material_create(S.MAT_STANDART, texture_id=t_check),
+        material_create(S.MAT_STANDART, color=(0.8, 0.2, 0.15, 0)),
+        material_create(S.MAT_GLASS, color=(0.9, 0.95, 1.0, 0), opacity=0.1),
+        material_create(S.MAT_WATER, color=(0.5, 0.7, 0.9, 0)),
+        material_create(S.MAT_VARNHISHED, texture_id=t_wood),
+        material_create(S.MAT_METAL, color=(0.9, 0.9, 0.9, 0)),
+        material_create(S.MAT_VARNHISHED, color=(0.2, 0.6, 0.3, 0)),
+        material_create(S.MAT_STANDART, color=(0.2, 0.3, 0.8, 0)),
+        material_create(S.MAT_STANDART, color=(0.8, 0.8, 0.8, 0)),
+    ], dtype=S.Material)
+
+    parts = []
+    # textured floor, 8x8 quads with uv tiling
+    g = 8
+    xs = np.linspace(-6, 6, g + 1)
+    for i in range(g):
+        for j in range(g):
+            a, b, c, d = (xs[i], xs[j], 0), (xs[i + 1], xs[j], 0), (xs[i + 1], xs[j + 1], 0), (xs[i], xs[j + 1], 0)
+            s1, s2, s3 = _quad(a, b, c, d)
+            uv = np.array([[(i, j), (i + 1, j), (i + 1, j + 1)], [(i, j), (i + 1, j + 1), (i, j + 1)]], f32) * f32(0.5)
+            parts.append(triangle_create(s1, s2, s3, uvp=uv, uvn=uv, mat_pos=M["floor"], mat_neg=M["blue"]))
+    # back wall: two-sided, different materials, fallback normals (zero -> N with w=1)
+    s1, s2, s3 = _quad((-6, 6, 0), (6, 6, 0), (6, 6, 5), (-6, 6, 5))
+    parts.append(triangle_create(s1, s2, s3, normals=np.zeros((2, 3, 3), f32), mat_pos=M["red"], mat_neg=M["white"]))
+    # side wall
+    s1, s2, s3 = _quad((-6, -6, 0), (-6, 6, 0), (-6, 6, 5), (-6, -6, 5))
+    parts.append(triangle_create(s1, s2, s3, mat_pos=M["varnish"], mat_neg=M["varnish"]))
+    parts.append(_sphere_tris((-2.5, 0.5, 1.3), 1.3, 2, M["glass"]))
+    parts.append(_sphere_tris((1.0, 2.0, 1.0), 1.0, 2, M["varnish_tex"]))
+    parts.append(_sphere_tris((2.8, -1.5, 0.8), 0.8, 1, M["metal"], smooth=False))
+    parts.append(_sphere_tris((0.0, -2.5, 0.7), 0.7, 2, M["red"], mat_neg=M["blue"]))
+    # water sheet over part of the floor
+    s1, s2, s3 = _quad((-6, -6, 0.4), (0, -6, 0.4), (0, -1, 0.4), (-6, -1, 0.4))
+    parts.append(triangle_create(s1, s2, s3, mat_pos=M["water"], mat_neg=M["water"]))
+    tris = _concat_tris(parts)
+
+    lights = np.array([
+        light_point((3.0, -4.0, 6.0), color=(1, 0.95, 0.9, 1), power=40.0),
+        light_spot((-4.0, -4.0, 7.0), (0.5, 0.6, -1.0), cone_angle=0.7, penumbra_angle=0.3, color=(0.9, 0.9, 1, 1),
+                   intensity=1.5),
+        light_directional((-0.3, 0.4, -1.0), color=(1, 1, 0.9, 1), power=0.6),
+    ], dtype=S.Light)
+    span = 0.9
+    pos, d, r, u = camera((0.5, -11.0, 3.5), (0, 1, -0.22), (span, 0, 0), (0, 0.22 * span * height / width, span * height / width))
+    return Scene(tris, lights, mats, np.array(textures, dtype=S.Texture), np.concatenate(texels), sky, pos, d, r, u,
+                 name="matmix")
+
+
+def build(name, width, height):
+    """Named scenes used by tests, fixtures and the bench."""
+    if name == "cornell":
+        return cornell_box(width, height)
+    if name == "matmix":
+        return material_mix(width, height)
+    if name.startswith("tris"):
+        spec = name[4:]
+        n = int(spec[:-1]) * {"k": 1000, "m": 1000000}[spec[-1]] if spec[-1] in "km" else int(spec)
+        return random_triangles(n, width, height)
+    raise ValueError(f"unknown scene {name!r}")

@@ -1,0 +1,876 @@
+/*
+ * pt_oracle.c - CPU oracle (TEST INFRASTRUCTURE, see pt_oracle.h).
+ *
+ * Scalar restatement of Kernel/PathTracer_FullKernel.cl ("cl:") and
+ * Kernel/PathTracer_FullKernel_header.cl ("h:") of the reference.  OpenCL C
+ * semantics are spelled out where C differs: float4 arithmetic is on all four
+ * components, dot/length/normalize are 4-component, unsuffixed literals are
+ * double, size_t/uint/int promotions follow C.
+ *
+ * Build with -O2 -ffp-contract=off and WITHOUT -march=native / -ffast-math:
+ * every + - * / sqrt below must be one correctly rounded binary32 operation.
+ */
+#include "pt_oracle.h"
+#include "ptmi_detmath.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* float4 helpers: OpenCL vector semantics                                    */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { float x, y, z, w; } f4;
+
+static inline f4 mk4(float x, float y, float z, float w) { f4 r = { x, y, z, w }; return r; }
+static inline f4 ld4(const ptmi_float4* p) { return mk4(p->x, p->y, p->z, p->w); }
+static inline f4 add4(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static inline f4 sub4(f4 a, f4 b) { return mk4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+static inline f4 mul4(f4 a, f4 b) { return mk4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+static inline f4 scale4(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline f4 div4s(f4 a, float s) { return mk4(a.x / s, a.y / s, a.z / s, a.w / s); }
+static inline f4 neg4(f4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
+
+/* dot(float4,float4): 4-component; association order fixed as ((x+y)+z)+w */
+static inline float dot4(f4 a, f4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+/* length = sqrt(dot); normalize = true division of every component */
+static inline float length4(f4 a) { return sqrtf(dot4(a, a)); }
+static inline f4 normalize4(f4 a) { return div4s(a, length4(a)); }
+/* cross(float4,float4): xyz cross, w = 0 (OpenCL 1.2 6.12.5) */
+static inline f4 cross4(f4 a, f4 b)
+{
+    return mk4(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f);
+}
+/* OpenCL max(float,float): "y if x < y, otherwise x" */
+static inline float cl_max(float x, float y) { return x < y ? y : x; }
+
+/* h:10-16 */
+#define PATH_PI 3.14159265f
+#define PATH_PI_INVERSE 0.31830988618f
+#define MIN_REFLECTION_NUMBER 5
+#define MIN_CONTRIBUTION_VALUE 0.001f
+/* h:166-169 */
+#define MATERIAL_N_WATER 1.333f
+#define MATERIAL_N_GLASS 1.55f
+#define MATERIAL_N_VARNISH 3.f
+#define MATERIAL_KSCHLICK 0.8f
+
+/* device Ray3D, h:89-107 */
+typedef struct {
+    f4 origin, direction, inverse;
+    float sample_x, sample_y;
+    uint32_t num_bbx, num_tri, reflection_id;
+    int is_in_water;
+    f4 point;  /* intersectionPoint */
+    f4 color;  /* intersectionColor */
+    uint32_t triangle_id, material_id;
+    float s, t;
+} ray_t;
+
+/* ------------------------------------------------------------------------- */
+/* RNG and samplers                                                           */
+/* ------------------------------------------------------------------------- */
+
+/* random(), h:246-253: seed = (16807 * (ulong)seed) & 0x7FFFFFFF (the int is
+ * sign-extended to ulong), result = (float)seed / (float)0x7FFFFFFF (=2^31). */
+float pto_random(int32_t* seed)
+{
+    const uint64_t a = 16807u;
+    const uint64_t m = 0x7FFFFFFFu;
+    *seed = (int32_t)((a * (uint64_t)(int64_t)*seed) & m);
+    return (float)*seed / (float)m;
+}
+
+/* InitializeRandomSeed(), h:255-264: everything ends up modulo 2^32. */
+int32_t pto_initialize_random_seed(uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration)
+{
+    uint32_t s = gx + gy * w + iteration * w * h;
+    s *= 2011u;
+    s *= s;
+    if (s == 0u) s = 1u;
+    return (int32_t)s;
+}
+
+/* sampler(), cl:1119-1150 */
+void pto_sampler(uint32_t kind, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration,
+                 int32_t* seed, float sample[2])
+{
+    if (kind == PTMI_SAMPLER_UNIFORM) { /* cl:1123-1135 */
+        const int sample_id = (int)(iteration % 9u);
+        float sx = (float)gx, sy = (float)gy;
+        float ox = (float)(sample_id % 3), oy = (float)(sample_id / 3);
+        ox += 0.5f; oy += 0.5f;
+        ox /= 3.f;  oy /= 3.f;
+        sx += ox;   sy += oy;
+        sx /= (float)w; sy /= (float)h;
+        sx -= 0.5f; sy -= 0.5f;
+        sample[0] = sx; sample[1] = sy;
+    } else if (kind == PTMI_SAMPLER_RANDOM) { /* cl:1137-1141 */
+        float sx = pto_random(seed);
+        float sy = pto_random(seed);
+        sx *= 0.9f;  sy *= 0.9f;
+        sx += 0.05f; sy += 0.05f;
+        sx -= 0.5f;  sy -= 0.5f;
+        sample[0] = sx; sample[1] = sy;
+    } else { /* JITTERED, cl:1145-1146 */
+        sample[0] = (((float)gx + 0.9f * pto_random(seed)) + 0.05f) / (float)w - 0.5f;
+        sample[1] = (((float)gy + 0.9f * pto_random(seed)) + 0.05f) / (float)h - 0.5f;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Ray helpers, h:276-295                                                     */
+/* ------------------------------------------------------------------------- */
+
+static void ray_set_direction(ray_t* r, f4 d)
+{
+    r->direction = normalize4(d);
+    r->inverse.x = 1.0f / r->direction.x;
+    r->inverse.y = 1.0f / r->direction.y;
+    r->inverse.z = 1.0f / r->direction.z;
+    r->inverse.w = 0.0f;
+}
+
+static void ray_create(ray_t* r, f4 o, f4 d, int in_water)
+{
+    r->origin = o;
+    r->is_in_water = in_water;
+    r->num_bbx = 0;
+    r->num_tri = 0;
+    r->reflection_id = 0;
+    r->sample_x = 0.0f;
+    r->sample_y = 0.0f;
+    ray_set_direction(r, d);
+}
+
+/* Vector_PutInSameHemisphereAs, h:237-244 */
+static f4 put_in_same_hemisphere(f4 v, f4 n)
+{
+    const float d = dot4(v, n);
+    if (d < 0.001f) v = add4(v, scale4(n, 0.01f - d));
+    return v;
+}
+
+/* ------------------------------------------------------------------------- */
+/* BoundingBox_Intersects, cl:64-139                                          */
+/* ------------------------------------------------------------------------- */
+
+static int bbox_intersects(const ptmi_bounding_box* bb, ray_t* r, float squared_distance)
+{
+    float t_min, t_max, ty_min, ty_max, tz_min, tz_max;
+
+    r->num_bbx++; /* cl:66, counted before the isEmpty test */
+    if (bb->is_empty) return 0;
+
+    if (r->direction.x > 0) {
+        t_min = (bb->p_min.x - r->origin.x) * r->inverse.x;
+        t_max = (bb->p_max.x - r->origin.x) * r->inverse.x;
+    } else {
+        t_min = (bb->p_max.x - r->origin.x) * r->inverse.x;
+        t_max = (bb->p_min.x - r->origin.x) * r->inverse.x;
+    }
+    if (t_min < 0 && t_max < 0) return 0;
+
+    if (r->direction.y > 0) {
+        ty_min = (bb->p_min.y - r->origin.y) * r->inverse.y;
+        ty_max = (bb->p_max.y - r->origin.y) * r->inverse.y;
+    } else {
+        ty_min = (bb->p_max.y - r->origin.y) * r->inverse.y;
+        ty_max = (bb->p_min.y - r->origin.y) * r->inverse.y;
+    }
+    if (ty_min < 0 && ty_max < 0) return 0;
+    if (t_min > ty_max || ty_min > t_max) return 0;
+    if (ty_min > t_min) t_min = ty_min;
+    if (ty_max < t_max) t_max = ty_max;
+
+    if (r->direction.z > 0) {
+        tz_min = (bb->p_min.z - r->origin.z) * r->inverse.z;
+        tz_max = (bb->p_max.z - r->origin.z) * r->inverse.z;
+    } else {
+        tz_min = (bb->p_max.z - r->origin.z) * r->inverse.z;
+        tz_max = (bb->p_min.z - r->origin.z) * r->inverse.z;
+    }
+    if (tz_min < 0 && tz_max < 0) return 0;
+    if (t_min > tz_max || tz_min > t_max) return 0;
+    if (tz_min > t_min) t_min = tz_min;
+    if (tz_max < t_max) t_max = tz_max;
+
+    if (t_min < 0) return 1;               /* origin inside the box, cl:132 */
+    if (t_min > squared_distance) return 0; /* linear t vs "squared" distance, cl:135 (quirk kept) */
+    return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Textures, h:430-459; sky, cl:438-512                                       */
+/* ------------------------------------------------------------------------- */
+
+static f4 texture_pixel(const ptmi_texture* tex, const ptmi_uchar4* data, float u, float v)
+{
+    uint32_t x, y;
+    u = u - (float)((int)u) + (float)(u < 0 ? 1 : 0);
+    v = v - (float)((int)v) + (float)(v < 0 ? 1 : 0);
+    x = (uint32_t)(u * (float)(tex->width - 1u));
+    y = (uint32_t)(v * (float)(tex->height - 1u));
+    {
+        const uint32_t index = tex->offset + y * tex->width + x;
+        const ptmi_uchar4 p = data[index];
+        f4 c = mk4((float)p.x / 255.f, (float)p.y / 255.f, (float)p.z / 255.f, (float)p.w / 255.f);
+        c.w = 1.f - c.w;
+        return c;
+    }
+}
+
+static f4 sky_color(const ptmi_sky* sky, const ptmi_uchar4* data, f4 d)
+{
+    const float x = sky->cos_rotation_angle * d.x - sky->sin_rotation_angle * d.y;
+    const float y = sky->sin_rotation_angle * d.x + sky->cos_rotation_angle * d.y;
+    const float z = d.z;
+    int face = 0;
+    float u = 0, v = 0;
+
+    if (fabsf(z) > fabsf(x) && fabsf(z) > fabsf(y)) {
+        if (z > 0) { face = 5; u = (1 - x / z) / 2; v = (1 + y / z) / 2; }
+        else       { face = 0; u = (1 + x / z) / 2; v = (1 + y / z) / 2; }
+    } else if (fabsf(x) > fabsf(y) && fabsf(x) > fabsf(z)) {
+        if (x > 0) { face = 1; u = (1 - y / x) / 2; v = (1 + z / x) / 2; }
+        else       { face = 3; u = (1 - y / x) / 2; v = (1 - z / x) / 2; }
+    } else if (fabsf(y) > fabsf(x) && fabsf(y) > fabsf(z)) {
+        if (y > 0) { face = 4; u = (1 + x / y) / 2; v = (1 + z / y) / 2; }
+        else       { face = 2; u = (1 + x / y) / 2; v = (1 - z / y) / 2; }
+    }
+    return texture_pixel(&sky->sky_textures[face], data, u, v); /* Sky_GetFaceColorValue, cl:497-512 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* Triangle, cl:519-610                                                       */
+/* ------------------------------------------------------------------------- */
+
+/* Triangle_GetColorValueAt, cl:591-602 */
+static f4 triangle_color_at(const pto_scene* sc, const ptmi_triangle* tri, int positive_normal, float s, float t)
+{
+    const ptmi_material* mat = &sc->materiaux[positive_normal ? tri->mat_pos : tri->mat_neg];
+    float u, v;
+    const float b = (1 - s) - t;
+    if (mat->is_simple_color) return ld4(&mat->simple_color);
+    if (positive_normal) {
+        u = (tri->uvp1.x * b + tri->uvp2.x * s) + tri->uvp3.x * t;
+        v = (tri->uvp1.y * b + tri->uvp2.y * s) + tri->uvp3.y * t;
+    } else {
+        u = (tri->uvn1.x * b + tri->uvn2.x * s) + tri->uvn3.x * t;
+        v = (tri->uvn1.y * b + tri->uvn2.y * s) + tri->uvn3.y * t;
+    }
+    return texture_pixel(&sc->textures[mat->texture_id], sc->textures_data, u, v);
+}
+
+/* Triangle_Intersects, cl:519-589.  `shade` = fetch the colour as the
+ * reference does on every accepted hit (cl:568-570); the shadow traversal
+ * never reads it so it passes 0 there. */
+static int triangle_intersects(const pto_scene* sc, const ptmi_triangle* tri, ray_t* r, float* squared_distance,
+                               int shade)
+{
+    const f4 S1 = ld4(&tri->s1), S2 = ld4(&tri->s2), S3 = ld4(&tri->s3), N = ld4(&tri->n);
+    r->num_tri++;
+    {
+        const f4 u = sub4(S2, S1);
+        const f4 v = sub4(S3, S1);
+        const float d = dot4(N, S1);
+        const float nd = dot4(N, r->direction);
+        f4 q, full_ray, w;
+        float nsd, uv, wv, wu, uu, vv, denom, s, t;
+
+        if ((nd > -0.00001f) && (nd < 0.00001f)) return 0;
+
+        q = add4(r->origin, scale4(r->direction, (d - dot4(N, r->origin)) / nd));
+        full_ray = sub4(q, r->origin);
+        nsd = dot4(full_ray, full_ray);
+        if (nsd > *squared_distance) return 0;
+        if (nsd < 0.00001f) return 0;
+
+        w = sub4(q, S1);
+        uv = dot4(u, v); wv = dot4(w, v); wu = dot4(w, u); uu = dot4(u, u); vv = dot4(v, v);
+        denom = 1 / (uv * uv - uu * vv);
+        s = (uv * wv - vv * wu) * denom;
+        t = (uv * wu - uu * wv) * denom;
+        if (s < 0 || t < 0 || s + t > 1) return 0;
+        if (dot4(full_ray, r->direction) < 0) return 0;
+
+        r->material_id = nd < 0 ? tri->mat_pos : tri->mat_neg;
+        if (shade) r->color = triangle_color_at(sc, tri, nd < 0, s, t);
+        *squared_distance = nsd;
+        r->s = s;
+        r->t = t;
+        r->point = q;
+        return 1;
+    }
+}
+
+/* Triangle_GetSmoothNormal, cl:604-610 */
+static f4 triangle_smooth_normal(const ptmi_triangle* tri, int positive_normal, float s, float t)
+{
+    const f4 n = normalize4(add4(add4(scale4(ld4(&tri->n2), s), scale4(ld4(&tri->n3), t)),
+                                 scale4(ld4(&tri->n1), (1 - s) - t)));
+    return positive_normal ? n : neg4(n);
+}
+
+/* ------------------------------------------------------------------------- */
+/* BVH traversal, cl:620-783                                                  */
+/* ------------------------------------------------------------------------- */
+
+static float dir_component(const f4* d, uint32_t axis) { return ((const float*)d)[axis]; }
+
+/* BVH_IntersectRay, cl:620-702: closest hit, near child first, far pushed. */
+static int bvh_intersect_ray(const pto_scene* sc, ray_t* r)
+{
+    float squared_distance = INFINITY;
+    int has_intersection = 0;
+    int top = -1;
+    const ptmi_node* current = &sc->bvh[0];
+    const ptmi_node* stack[PTMI_BVH_MAX_DEPTH];
+
+    for (;;) {
+        if (current->is_leaf) {
+            uint32_t i;
+            for (i = current->triangle_start_index; i < current->triangle_start_index + current->nb_triangles; i++) {
+                if (triangle_intersects(sc, &sc->triangulation[i], r, &squared_distance, 1)) {
+                    r->triangle_id = i;
+                    has_intersection = 1;
+                }
+            }
+            if (top < 0) break;
+            current = stack[top--];
+        } else {
+            const ptmi_node *son1, *son2;
+            int b1, b2;
+            if (dir_component(&r->direction, current->cut_axis) > 0) {
+                son1 = &sc->bvh[current->son1_id];
+                son2 = &sc->bvh[current->son2_id];
+            } else {
+                son2 = &sc->bvh[current->son1_id];
+                son1 = &sc->bvh[current->son2_id];
+            }
+            b1 = bbox_intersects(&son1->triangles_aabb, r, squared_distance);
+            b2 = bbox_intersects(&son2->triangles_aabb, r, squared_distance);
+            if (b1) {
+                if (b2) {
+                    if (top + 1 >= PTMI_BVH_MAX_DEPTH) abort(); /* reference would overrun stack[30] */
+                    stack[++top] = son2;
+                }
+                current = son1;
+            } else if (b2) {
+                current = son2;
+            } else {
+                if (top < 0) break;
+                current = stack[top--];
+            }
+        }
+    }
+    return has_intersection;
+}
+
+/* BVH_IntersectShadowRay, cl:705-783: any hit; `squared_distance` receives the
+ * LINEAR light distance from the caller (cl:938-944, quirk kept). */
+static int bvh_intersect_shadow_ray(const pto_scene* sc, ray_t* r, float squared_distance)
+{
+    int top = -1;
+    const ptmi_node* current = &sc->bvh[0];
+    const ptmi_node* stack[PTMI_BVH_MAX_DEPTH];
+
+    for (;;) {
+        if (current->is_leaf) {
+            uint32_t i;
+            for (i = current->triangle_start_index; i < current->triangle_start_index + current->nb_triangles; i++)
+                if (triangle_intersects(sc, &sc->triangulation[i], r, &squared_distance, 0)) return 1;
+            if (top < 0) break;
+            current = stack[top--];
+        } else {
+            const ptmi_node *son1, *son2;
+            int b1, b2;
+            if (dir_component(&r->direction, current->cut_axis) > 0) {
+                son1 = &sc->bvh[current->son1_id];
+                son2 = &sc->bvh[current->son2_id];
+            } else {
+                son2 = &sc->bvh[current->son1_id];
+                son1 = &sc->bvh[current->son2_id];
+            }
+            b1 = bbox_intersects(&son1->triangles_aabb, r, squared_distance);
+            b2 = bbox_intersects(&son2->triangles_aabb, r, squared_distance);
+            if (b1) {
+                if (b2) {
+                    if (top + 1 >= PTMI_BVH_MAX_DEPTH) abort();
+                    stack[++top] = son2;
+                }
+                current = son1;
+            } else if (b2) {
+                current = son2;
+            } else {
+                if (top < 0) break;
+                current = stack[top--];
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Materials, cl:166-416                                                      */
+/* ------------------------------------------------------------------------- */
+
+/* shared body of the three Fresnel functions (cl:192-292) */
+static float fresnel_fraction(float n1, float n2, float cos1, f4 incident, f4 N, f4* refraction_dir)
+{
+    const float sin1 = sqrtf(1 - cos1 * cos1);
+    const float sin2 = n1 * sin1 / n2;
+    float cos2, r_para, r_perp;
+    if (sin2 >= 1) return 1;
+    cos2 = sqrtf(1 - sin2 * sin2);
+    r_para = (n2 * cos1 - n1 * cos2) / (n2 * cos1 + n1 * cos2);
+    r_perp = (n1 * cos1 - n2 * cos2) / (n1 * cos1 + n2 * cos2);
+    if (refraction_dir)
+        *refraction_dir = add4(scale4(incident, n1 / n2), scale4(N, n1 / n2 * cos1 - cos2)); /* cl:249,289 */
+    return (r_para * r_para + r_perp * r_perp) / 2.0f;
+}
+
+/* Material_FresnelGlassReflectionFraction, cl:192-217 */
+static float fresnel_glass(f4 incident, f4 N)
+{
+    return fresnel_fraction(1, MATERIAL_N_GLASS, -dot4(incident, N), incident, N, NULL);
+}
+
+/* Material_FresnelWaterReflectionFraction, cl:219-254.  On total reflection the
+ * reference returns before writing its outputs; callers only read them in the
+ * refraction branch, which needs random < 1 ... which random()==1.0 excludes
+ * too, so the uninitialised values are never consumed. */
+static float fresnel_water(f4 incident, f4 N, int already_in_water, f4* refraction_dir, float* mult)
+{
+    float n1, n2, f;
+    if (already_in_water) { n1 = MATERIAL_N_WATER; n2 = 1; } else { n1 = 1; n2 = MATERIAL_N_WATER; }
+    f = fresnel_fraction(n1, n2, -dot4(incident, N), incident, N, refraction_dir);
+    if (mult) *mult = (n2 * n2) / (n1 * n1);
+    return f;
+}
+
+/* Material_FresnelVarnishReflectionFraction, cl:256-292 (isInVarnish is always false on the live path) */
+static float fresnel_varnish(f4 incident, f4 N, f4* refraction_dir)
+{
+    const float cos1 = fmaxf(0.f, fminf(1.f, -dot4(incident, N)));
+    return fresnel_fraction(1.0f, MATERIAL_N_VARNISH, cos1, incident, N, refraction_dir);
+}
+
+/* Material_FresnelReflection, cl:294-300 */
+static f4 fresnel_reflection(f4 v, f4 N) { return sub4(v, scale4(N, 2 * dot4(v, N))); }
+
+/* Material_BRDF, cl:166-190 */
+static float material_brdf(const ptmi_material* mat, f4 incident, f4 N, f4 reflected)
+{
+    if (mat->type == PTMI_MAT_STANDART) return PATH_PI_INVERSE;
+    if (mat->type == PTMI_MAT_GLASS) return 1;
+    if (mat->type == PTMI_MAT_WATER) {
+        const float denom = 1 + MATERIAL_KSCHLICK * dot4(incident, reflected);
+        return (1 - MATERIAL_KSCHLICK * MATERIAL_KSCHLICK) / (4 * PATH_PI * denom * denom);
+    }
+    if (mat->type == PTMI_MAT_VARNHISHED) return (1 - fresnel_varnish(incident, N, NULL)) * PATH_PI_INVERSE;
+    return 1;
+}
+
+/* Material_ConcentricSampleDisk, cl:339-416 */
+void pto_concentric_sample_disk(int32_t* seed, float* dx, float* dy)
+{
+    const float u1 = pto_random(seed);
+    const float u2 = pto_random(seed);
+    float r, theta, sn, cs;
+    const float sx = 2 * u1 - 1;
+    const float sy = 2 * u2 - 1;
+
+    if (fabsf(sx) < 0.0001f) { r = sy; theta = 0; }
+    else if (fabsf(sy) < 0.0001f) { r = sx; theta = 2; }
+    else if (sx > -sy) {
+        if (sx > sy) { r = sx; if (sy > 0) theta = sy / sx; else theta = 8.f + sy / sx; }
+        else { r = sy; theta = 2.f - sx / sy; }
+    } else {
+        if (sx < sy) { r = -sx; theta = 4.f + sy / sx; }
+        else { r = -sy; theta = 6.f - sy / sx; }
+    }
+    theta *= PATH_PI / 4.f;
+    r = (float)((double)r * 0.999); /* cl:408: unsuffixed literal => double multiply */
+    ptmi_sincosf(theta, &sn, &cs);
+    *dx = r * cs;
+    *dy = r * sn;
+}
+
+/* Material_CosineSampleHemisphere, cl:303-336 */
+static f4 cosine_sample_hemisphere(int32_t* seed, f4 N)
+{
+    float x, y, z;
+    f4 v, sn, tn;
+    pto_concentric_sample_disk(seed, &x, &y);
+    z = 1 - x * x - y * y;
+    z = (z < 0) ? 0 : sqrtf(z);
+    v = mk4(x, y, z, 0);
+    if (N.z > 0.9999f) return v;
+    if (N.z < -0.9999f) return neg4(v);
+    sn = normalize4(mk4(-N.y, N.x, 0, 0));
+    tn = normalize4(cross4(N, sn));
+    return normalize4(mk4(dot4(mk4(sn.x, tn.x, N.x, 0), v),
+                          dot4(mk4(sn.y, tn.y, N.y, 0), v),
+                          dot4(mk4(sn.z, tn.z, N.z, 0), v), 0));
+}
+
+/* Light_PowerToward, h:403-421 */
+static float light_power_toward(const ptmi_light* l, f4 p, f4 N)
+{
+    const f4 pos = ld4(&l->position), dir = ld4(&l->direction);
+    if (l->type == PTMI_LIGHT_DIRECTIONNAL) return l->power * fmaxf(dot4(neg4(dir), N), 0.f);
+    if (l->type == PTMI_LIGHT_POINT) {
+        const f4 d = sub4(p, pos); /* Vector_SquaredDistanceTo(&position, p): temp = p - position, h:231 */
+        return l->power / dot4(d, d) * fmaxf(dot4(normalize4(sub4(pos, p)), N), 0.f);
+    }
+    if (l->type == PTMI_LIGHT_SPOT) {
+        const f4 lrd = normalize4(sub4(p, pos));
+        const float cos_angle = dot4(lrd, dir);
+        if (cos_angle > l->cos_inner) return l->power * fmaxf(-dot4(lrd, N), 0.f);
+        if (cos_angle < l->cos_outer) return 0.0f;
+        return l->power * (cos_angle - l->cos_outer) / (l->cos_inner - l->cos_outer) * fmaxf(-dot4(lrd, N), 0);
+    }
+    return 0.f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Scene, cl:791-954                                                          */
+/* ------------------------------------------------------------------------- */
+
+/* Scene_ComputeDirectIllumination, cl:901-954 */
+static f4 compute_direct_illumination(const pto_scene* sc, ray_t* cam, const ptmi_material* mat, f4 N,
+                                      pto_totals* totals)
+{
+    f4 L = mk4(0, 0, 0, 0);
+    const f4 tint = mk4(1, 1, 1, 1);
+    uint32_t i;
+    for (i = 0; i < sc->lights_size; i++) {
+        const ptmi_light* light = &sc->lights[i];
+        ray_t lr;
+        const f4 full_ray = light->type == PTMI_LIGHT_DIRECTIONNAL ? neg4(ld4(&light->direction))
+                                                                   : sub4(ld4(&light->position), cam->point);
+        float light_distance, brdf;
+        ray_create(&lr, cam->point, full_ray, cam->is_in_water);
+        light_distance = light->type == PTMI_LIGHT_DIRECTIONNAL ? INFINITY : length4(full_ray);
+        brdf = material_brdf(mat, neg4(lr.direction), N, cam->direction);
+        if (totals) totals->shadow_rays++;
+        if (!bvh_intersect_shadow_ray(sc, &lr, light_distance))
+            L = add4(L, mul4(scale4(tint, light_power_toward(light, cam->point, N) * brdf), ld4(&light->color)));
+        cam->num_bbx += lr.num_bbx;
+        cam->num_tri += lr.num_tri;
+    }
+    return L;
+}
+
+/* Scene_ComputeRadiance, cl:791-891 */
+static f4 compute_radiance(ray_t* r, int32_t* seed, const ptmi_material* mat, f4 direct, f4* transfer, f4 Ng, f4 Ns,
+                           f4* out_dir_dbg)
+{
+    f4 N = r->direction;
+    f4 radiance = mk4(0, 0, 0, 0);
+    f4 out = r->direction;
+
+    if (mat->type == PTMI_MAT_STANDART) {
+        *transfer = mul4(*transfer, r->color);
+        radiance = mul4(direct, *transfer);
+        out = cosine_sample_hemisphere(seed, Ns);
+        N = Ns;
+    } else if (mat->type == PTMI_MAT_GLASS) {
+        const float f = fresnel_glass(r->direction, Ns);
+        if (pto_random(seed) < f) {
+            out = fresnel_reflection(r->direction, Ns);
+            N = Ng;
+        } else {
+            *transfer = mul4(*transfer, scale4(r->color, 1 - mat->opacity));
+            N = r->direction;
+        }
+    } else if (mat->type == PTMI_MAT_WATER) {
+        f4 refracted = mk4(0, 0, 0, 0);
+        float mult = 0;
+        const float f = fresnel_water(r->direction, Ns, r->is_in_water, &refracted, &mult);
+        if (pto_random(seed) < f) {
+            out = fresnel_reflection(r->direction, Ns);
+            N = Ng;
+        } else {
+            r->is_in_water = !r->is_in_water;
+            out = refracted;
+            N = neg4(Ng);
+            *transfer = scale4(*transfer, mult);
+        }
+    } else if (mat->type == PTMI_MAT_VARNHISHED) {
+        f4 refracted;
+        float f1;
+        radiance = add4(radiance, mul4(mul4(direct, r->color), *transfer));
+        f1 = fresnel_varnish(r->direction, Ns, &refracted);
+        if (pto_random(seed) < f1) {
+            out = fresnel_reflection(r->direction, Ns);
+        } else {
+            out = cosine_sample_hemisphere(seed, Ns);
+            *transfer = mul4(*transfer, r->color);
+        }
+    }
+
+    out = put_in_same_hemisphere(out, N);
+    ray_set_direction(r, out);
+    r->origin = add4(r->point, scale4(out, 0.001f)); /* cl:880: the un-normalised out direction */
+    if (out_dir_dbg) *out_dir_dbg = out;
+    return radiance;
+}
+
+/* ------------------------------------------------------------------------- */
+/* superSamplingStopCriteria, cl:1152-1172                                    */
+/* ------------------------------------------------------------------------- */
+
+static void sample_to_pixel(const pto_scene* sc, float sx, float sy, int* px, int* py)
+{
+    /* cl:1333-1334 / cl:1159-1160: (sample + 0.5) is a DOUBLE add and multiply */
+    int x = (int)(((double)sx + 0.5) * (int)sc->image_width);
+    int y = (int)(((double)sy + 0.5) * (int)sc->image_height);
+    if (x > (int)sc->image_width - 1) x = (int)sc->image_width - 1;
+    if (y > (int)sc->image_height - 1) y = (int)sc->image_height - 1;
+    *px = x; *py = y;
+}
+
+static int super_sampling_stop(const pto_scene* sc, const pto_buffers* out, const ray_t* r, int32_t* seed)
+{
+    int px, py, off;
+    float n, sx, sy, sz, sigma2_n;
+    sample_to_pixel(sc, r->sample_x, r->sample_y, &px, &py);
+    off = py * (int)sc->image_width + px;
+    n = out->image_ray_nb[off];
+    sx = out->image_v[4 * off + 0] / n;
+    sy = out->image_v[4 * off + 1] / n;
+    sz = out->image_v[4 * off + 2] / n;
+    sigma2_n = fmaxf(fmaxf(sx, sy), sz);
+    return (double)pto_random(seed) > (double)(100 * sigma2_n / sc->x2inv[(uint32_t)n]) + 0.05;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Kernel_Main, cl:1180-1350                                                  */
+/* ------------------------------------------------------------------------- */
+
+static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint32_t iteration,
+                            const pto_buffers* out, pto_totals* totals, pto_bounce* trace, int max_trace,
+                            float radiance_out[4])
+{
+    ray_t r;
+    int32_t seed = pto_initialize_random_seed(gx, gy, sc->image_width, sc->image_height, iteration);
+    float sample[2];
+    f4 shot, radiance = mk4(0, 0, 0, 0), transfer = mk4(1, 1, 1, 1);
+    int active = 1, n_trace = 0;
+
+    pto_sampler(sc->sampler, gx, gy, sc->image_width, sc->image_height, iteration, &seed, sample);
+    shot = add4(add4(ld4(&sc->camera_direction), scale4(ld4(&sc->camera_right), sample[0])),
+                scale4(ld4(&sc->camera_up), sample[1]));
+    ray_create(&r, ld4(&sc->camera_position), shot, 0);
+    r.sample_x = sample[0];
+    r.sample_y = sample[1];
+    r.point = mk4(0, 0, 0, 0); r.color = mk4(0, 0, 0, 0);
+    r.triangle_id = 0; r.material_id = 0; r.s = 0; r.t = 0;
+
+    if (sc->super_sampling && out && iteration > MIN_REFLECTION_NUMBER && super_sampling_stop(sc, out, &r, &seed))
+        return 0; /* cl:1219-1222 */
+
+    while (active && r.reflection_id < sc->ray_max_depth) {
+        if (totals) totals->segments++;
+        if (bvh_intersect_ray(sc, &r)) {
+            const ptmi_triangle* tri = &sc->triangulation[r.triangle_id];
+            const ptmi_material* mat = &sc->materiaux[r.material_id];
+            const int same_dir = dot4(r.direction, ld4(&tri->n)) > 0;
+            const f4 Ng = !same_dir ? ld4(&tri->n) : neg4(ld4(&tri->n)); /* Triangle_GetNormal, h:500 */
+            f4 Ns = triangle_smooth_normal(tri, !same_dir, r.s, r.t);
+            f4 direct, out_dir, rad;
+            Ns = put_in_same_hemisphere(Ns, neg4(r.direction));
+            Ns = normalize4(Ns);
+            direct = compute_direct_illumination(sc, &r, mat, Ns, totals);
+            rad = compute_radiance(&r, &seed, mat, direct, &transfer, Ng, Ns, &out_dir);
+            radiance = add4(radiance, rad);
+            r.reflection_id++;
+            if (trace && n_trace < max_trace) {
+                pto_bounce* b = &trace[n_trace++];
+                b->triangle_id = r.triangle_id; b->material_id = r.material_id;
+                b->s = r.s; b->t = r.t;
+                memcpy(b->point, &r.point, 16); memcpy(b->ns, &Ns, 16); memcpy(b->out_dir, &out_dir, 16);
+                memcpy(b->transfer, &transfer, 16); memcpy(b->radiance, &radiance, 16);
+                b->seed_after = seed; b->n_bbx = r.num_bbx; b->n_tri = r.num_tri;
+            }
+        } else {
+            active = 0;
+            radiance = add4(radiance, mul4(sky_color(sc->sky, sc->textures_data, r.direction), transfer));
+        }
+        if (active) { /* cl:1296-1304 */
+            const float max_contribution = cl_max(transfer.x, cl_max(transfer.y, transfer.z));
+            if (max_contribution <= MIN_CONTRIBUTION_VALUE) active = 0;
+        }
+    }
+
+    if (radiance_out) memcpy(radiance_out, &radiance, 16);
+    if (totals) {
+        totals->paths++;
+        totals->surface_hits += r.reflection_id;
+        totals->box_tests += r.num_bbx;
+        totals->triangle_tests += r.num_tri;
+    }
+    if (!out) return n_trace > 0 ? n_trace : 1;
+
+    /* statistics, cl:1319-1331 */
+    if (out->ray_depths) out->ray_depths[r.reflection_id]++;
+    if (out->ray_intersected_bbx && r.num_bbx < PTMI_MAX_INTERSECTION_NUMBER) out->ray_intersected_bbx[r.num_bbx]++;
+    if (out->ray_intersected_tri && r.num_tri < PTMI_MAX_INTERSECTION_NUMBER) out->ray_intersected_tri[r.num_tri]++;
+
+    { /* framebuffer read-modify-write, cl:1333-1349 */
+        int px, py, off;
+        f4 before, after;
+        float n_before, n_after;
+        sample_to_pixel(sc, r.sample_x, r.sample_y, &px, &py);
+        off = py * (int)sc->image_width + px;
+        memcpy(&before, &out->image_color[4 * off], 16);
+        after = add4(before, radiance);
+        n_before = out->image_ray_nb[off];
+        n_after = n_before + 1.f;
+        out->image_ray_nb[off] = n_after;
+        memcpy(&out->image_color[4 * off], &after, 16);
+        if (out->image_v) {
+            if (iteration == 0) {
+                memset(&out->image_v[4 * off], 0, 16);
+            } else {
+                f4 v;
+                memcpy(&v, &out->image_v[4 * off], 16);
+                v = add4(v, mul4(sub4(radiance, div4s(before, n_before)), sub4(radiance, div4s(after, n_after))));
+                memcpy(&out->image_v[4 * off], &v, 16);
+            }
+        }
+    }
+    return 1;
+}
+
+int pto_kernel_main(const pto_scene* sc, uint32_t gx, uint32_t gy, uint32_t iteration, const pto_buffers* out,
+                    pto_totals* totals)
+{
+    return kernel_main_impl(sc, gx, gy, iteration, out, totals, NULL, 0, NULL);
+}
+
+int pto_trace_path(const pto_scene* sc, uint32_t gx, uint32_t gy, uint32_t iteration, pto_bounce* bounces,
+                   int max_bounces, float radiance_out[4])
+{
+    pto_scene s = *sc;
+    s.super_sampling = 0;
+    return kernel_main_impl(&s, gx, gy, iteration, NULL, NULL, bounces, max_bounces, radiance_out);
+}
+
+/* ------------------------------------------------------------------------- */
+/* driver                                                                     */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    const pto_scene* sc;
+    uint32_t first, n, y0, y1;
+    pto_buffers out; /* histograms are thread-private */
+    pto_totals totals;
+} worker_t;
+
+static void* worker_main(void* p)
+{
+    worker_t* w = (worker_t*)p;
+    uint32_t x, y, it;
+    for (y = w->y0; y < w->y1; y++)
+        for (x = 0; x < w->sc->image_width; x++)
+            for (it = w->first; it < w->first + w->n; it++)
+                pto_kernel_main(w->sc, x, y, it, &w->out, &w->totals);
+    return NULL;
+}
+
+void pto_render(const pto_scene* sc, uint32_t first, uint32_t n, const pto_buffers* out, int n_threads,
+                pto_totals* totals)
+{
+    const uint32_t H = sc->image_height, W = sc->image_width, D = sc->ray_max_depth;
+    pto_totals tt;
+    memset(&tt, 0, sizeof tt);
+
+    if (n_threads <= 1 || sc->sampler == PTMI_SAMPLER_RANDOM || sc->super_sampling) {
+        /* the reference's order: one full image per iteration (OpenCL.cpp:76-107) */
+        uint32_t it, x, y;
+        for (it = first; it < first + n; it++)
+            for (y = 0; y < H; y++)
+                for (x = 0; x < W; x++) pto_kernel_main(sc, x, y, it, out, &tt);
+    } else {
+        worker_t* ws;
+        pthread_t* th;
+        int i;
+        if ((uint32_t)n_threads > H) n_threads = (int)H;
+        ws = (worker_t*)calloc((size_t)n_threads, sizeof *ws);
+        th = (pthread_t*)calloc((size_t)n_threads, sizeof *th);
+        for (i = 0; i < n_threads; i++) {
+            worker_t* w = &ws[i];
+            w->sc = sc; w->first = first; w->n = n;
+            w->y0 = (uint32_t)((uint64_t)H * (uint64_t)i / (uint64_t)n_threads);
+            w->y1 = (uint32_t)((uint64_t)H * (uint64_t)(i + 1) / (uint64_t)n_threads);
+            w->out = *out;
+            w->out.ray_depths = (uint32_t*)calloc(D + 1, 4);
+            w->out.ray_intersected_bbx = (uint32_t*)calloc(PTMI_MAX_INTERSECTION_NUMBER, 4);
+            w->out.ray_intersected_tri = (uint32_t*)calloc(PTMI_MAX_INTERSECTION_NUMBER, 4);
+            pthread_create(&th[i], NULL, worker_main, w);
+        }
+        for (i = 0; i < n_threads; i++) {
+            uint32_t k;
+            worker_t* w = &ws[i];
+            pthread_join(th[i], NULL);
+            for (k = 0; k <= D; k++) if (out->ray_depths) out->ray_depths[k] += w->out.ray_depths[k];
+            for (k = 0; k < PTMI_MAX_INTERSECTION_NUMBER; k++) {
+                if (out->ray_intersected_bbx) out->ray_intersected_bbx[k] += w->out.ray_intersected_bbx[k];
+                if (out->ray_intersected_tri) out->ray_intersected_tri[k] += w->out.ray_intersected_tri[k];
+            }
+            free(w->out.ray_depths); free(w->out.ray_intersected_bbx); free(w->out.ray_intersected_tri);
+            tt.paths += w->totals.paths; tt.segments += w->totals.segments;
+            tt.surface_hits += w->totals.surface_hits; tt.shadow_rays += w->totals.shadow_rays;
+            tt.box_tests += w->totals.box_tests; tt.triangle_tests += w->totals.triangle_tests;
+        }
+        free(ws); free(th);
+    }
+    if (totals) *totals = tt;
+}
+
+/* ------------------------------------------------------------------------- */
+/* unit-level wrappers                                                        */
+/* ------------------------------------------------------------------------- */
+
+static f4 arr4(const float v[4]) { return mk4(v[0], v[1], v[2], v[3]); }
+
+int pto_bounding_box_intersects(const ptmi_bounding_box* bb, const float origin[4], const float direction[4],
+                                float squared_distance)
+{
+    ray_t r;
+    ray_create(&r, arr4(origin), arr4(direction), 0);
+    return bbox_intersects(bb, &r, squared_distance);
+}
+
+int pto_triangle_intersects(const ptmi_triangle* tri, const float origin[4], const float direction[4],
+                            float* squared_distance, float* s, float* t, float point[4])
+{
+    ray_t r;
+    int hit;
+    ray_create(&r, arr4(origin), arr4(direction), 0);
+    hit = triangle_intersects(NULL, tri, &r, squared_distance, 0);
+    if (hit) { *s = r.s; *t = r.t; memcpy(point, &r.point, 16); }
+    return hit;
+}
+
+void pto_cosine_sample_hemisphere(int32_t* seed, const float n[4], float out[4])
+{
+    const f4 v = cosine_sample_hemisphere(seed, arr4(n));
+    memcpy(out, &v, 16);
+}
+
+float pto_fresnel_glass(const float incident[4], const float n[4]) { return fresnel_glass(arr4(incident), arr4(n)); }
+float pto_fresnel_varnish(const float incident[4], const float n[4]) { return fresnel_varnish(arr4(incident), arr4(n), NULL); }
+
+void pto_sky_color(const ptmi_sky* sky, const ptmi_uchar4* data, const float direction[4], float rgba[4])
+{
+    const f4 c = sky_color(sky, data, arr4(direction));
+    memcpy(rgba, &c, 16);
+}
+
+void pto_sincos(float x, float* s, float* c) { ptmi_sincosf(x, s, c); }

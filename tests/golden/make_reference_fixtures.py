@@ -1,0 +1,58 @@
+"""Generates tests/golden/ref_<case>.npz by running the REFERENCE kernel on a GPU box.
+
+Run from the repo root on a machine with an MI355X and the prebuilt oracle/_ref/ files
+(`make -C oracle ref` where the reference tree exists, then e.g.
+`gpurun -- python tests/golden/make_reference_fixtures.py gpurun_out/golden`, then copy the .npz
+files into tests/golden/).  The scenes come from opencl_pathtracer_amd.scenes + the product BVH
+builder (itself pinned to the reference's BVH_Create by tests/test_bvh.py); the images, counts and
+histograms come from oracle/_ref/ref_kernel_<case>.hsaco = Kernel/PathTracer_FullKernel.cl compiled
+unmodified for gfx950.  Stored per case and iteration range: imageColor, imageRayNb, the three
+histograms, plus a digest of the scene arrays so a test can tell when the generator changed.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+import cases  # noqa: E402
+import oracle_ffi as O  # noqa: E402
+from opencl_pathtracer_amd import scenes, bvh_create  # noqa: E402
+
+
+def scene_digest(sc):
+    h = hashlib.sha256()
+    for a in (sc.bvh["son1Id"], sc.bvh["son2Id"], sc.bvh["triangleStartIndex"], sc.bvh["nbTriangles"],
+              sc.bvh["trianglesAABB"]["pMin"], sc.bvh["trianglesAABB"]["pMax"], sc.triangulation["S1"],
+              sc.triangulation["S2"], sc.triangulation["S3"], sc.triangulation["N"], sc.lights["position"],
+              sc.materiaux["simpleColor"], sc.texturesData):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def main(out_dir):
+    os.makedirs(out_dir, exist_ok=True)
+    for case, (name, sampler, w, h, d) in cases.CASES.items():
+        if not O.have_ref_kernel(case):
+            print("skip", case, "(no code object)")
+            continue
+        sc = bvh_create(scenes.build(name, w, h))
+        out = {"scene_digest": np.array(scene_digest(sc))}
+        for first, n in cases.FIXTURE_RANGES:
+            color, count, (dep, bbx, tri), ms = O.ref_gpu_render(case, sc, w, h, d, n, first_iteration=first)
+            tag = f"it{first}_{n}"
+            out[tag + "_color"] = color
+            out[tag + "_count"] = count
+            out[tag + "_depths"] = dep
+            nzb, nzt = np.flatnonzero(bbx), np.flatnonzero(tri)
+            out[tag + "_bbx_idx"], out[tag + "_bbx_val"] = nzb.astype(np.uint16), bbx[nzb]
+            out[tag + "_tri_idx"], out[tag + "_tri_val"] = nzt.astype(np.uint16), tri[nzt]
+            print(f"{case} [{first},{first + n}): {ms:.1f} ms, depths {dep.tolist()}", flush=True)
+        np.savez_compressed(os.path.join(out_dir, f"ref_{case}.npz"), **out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden"))

@@ -1,0 +1,155 @@
+"""GPU parity: the HIP integrator (through the C ABI) against the CPU oracle and against the reference itself.
+
+Bars:
+  * HIP vs oracle, JITTERED / UNIFORM samplers: BIT-EXACT images, histograms and counters (same numerics
+    contract, same accumulation order).
+  * HIP vs oracle, RANDOM sampler: samples land on arbitrary pixels and are added atomically (the reference
+    races there), so only fp32 summation order differs: per-channel RMS <= 1e-6, counts exact.
+  * HIP vs the reference kernel run on the same GPU (code object built from the unmodified .cl):
+    per-channel RMS of sum/n <= 1e-4 -- the tolerance BASELINE.json's north_star states.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+from opencl_pathtracer_amd import Backend, PtmiError, render_scene, structs as S
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-4  # north_star: "within 1e-4 per-channel RMS"
+
+
+@pytest.mark.parametrize("case", cases.SMALL)
+def test_bit_exact_vs_oracle(case, scene_factory):
+    name, sampler, w, h, d = cases.CASES[case]
+    sc = scene_factory(name, w, h)
+    spp = 6
+    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, spp, sampler=sampler)
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, spp, sampler=sampler)
+    assert np.array_equal(count, o_count)
+    assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert counters == totals
+    bad = np.argwhere(color.view(np.uint32) != o_color.view(np.uint32))
+    assert len(bad) == 0, f"{len(bad)} differing channel values, first at {bad[:5].tolist()}"
+
+
+def test_bit_exact_vs_oracle_1m_triangles(scene_factory):
+    name, sampler, w, h, d = cases.CASES["tris1m_160x90_d10"]
+    sc = scene_factory(name, w, h)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, 2)
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, 2)
+    assert counters == totals
+    assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
+
+
+def test_random_sampler_vs_oracle(scene_factory):
+    sc = scene_factory("cornell", 64, 48)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 8, sampler=S.RANDOM)
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 64, 48, 4, 8, sampler=S.RANDOM)
+    assert np.array_equal(count, o_count) and counters == totals and np.array_equal(dep, o_dep)
+    assert np.allclose(color, o_color, rtol=1e-5, atol=1e-5)
+    assert (cases.rms_per_channel(color, count, o_color, o_count) <= 1e-6).all()
+
+
+def test_iteration_ranges_compose(scene_factory):
+    """[0,16) in one launch == [0,8) then [8,16) on the same context, bit for bit (sequential accumulation);
+    and two contexts rendering the two shards sum to the same image up to fp32 rounding (spp sharding, 8e)."""
+    sc = scene_factory("matmix", 96, 96)
+    full, full_n, _, _ = render_scene(sc, 96, 96, 8, 16)
+    be = Backend().setup_context(96, 96, 8, sc.lightsSize)
+    be.initialize_memory(sc)
+    be.render(0, 8)
+    be.render(8, 8)
+    two, two_n = be.read_image()
+    be.release()
+    assert np.array_equal(full.view(np.uint32), two.view(np.uint32)) and np.array_equal(full_n, two_n)
+    a, an, _, _ = render_scene(sc, 96, 96, 8, 8, first_iteration=0)
+    b, bn, _, _ = render_scene(sc, 96, 96, 8, 8, first_iteration=8)
+    assert np.array_equal(an + bn, full_n)
+    assert (cases.rms_per_channel(a + b, an + bn, full, full_n) <= 1e-6).all()
+
+
+def test_clear_and_reinitialize(scene_factory):
+    sc = scene_factory("cornell", 64, 48)
+    be = Backend().setup_context(64, 48, 4, 1)
+    be.initialize_memory(sc)
+    be.render(0, 3)
+    first, _ = be.read_image()
+    be.clear()
+    zero, zero_n = be.read_image()
+    assert not zero.any() and not zero_n.any()
+    assert be.counters()["paths"] == 0
+    be.render(0, 3)
+    again, _ = be.read_image()
+    assert np.array_equal(first, again)
+    be.initialize_memory(sc)  # re-upload on the same context
+    be.render(0, 3)
+    third, _ = be.read_image()
+    be.release()
+    assert np.array_equal(first, third)
+
+
+def test_run_kernel_mirrors_reference_loop(scene_factory):
+    """OpenCL_RunKernel's contract: callback once per image after the readback, stats after the loop, release."""
+    sc = scene_factory("cornell", 64, 48)
+    calls = []
+    be = Backend().setup_context(64, 48, 4, 1)
+    be.initialize_memory(sc)
+    color, count, (dep, _, _), times = be.run_kernel(lambda: calls.append(1) or False, 5)
+    assert len(calls) == 5 and (count == 5).all() and dep.sum() == 64 * 48 * 5 and len(times) == 3
+    with pytest.raises(PtmiError):
+        be.render(0, 1)  # released, like the cl objects at OpenCL.cpp:120-139
+
+
+def test_histograms_can_be_disabled(scene_factory):
+    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS
+    sc = scene_factory("cornell", 64, 48)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 2, flags=FLAG_NO_HISTOGRAMS)
+    ref, _, _, ref_counters = render_scene(sc, 64, 48, 4, 2)
+    assert not dep.any() and not bbx.any() and not tri.any()
+    assert counters == ref_counters and np.array_equal(color, ref)
+
+
+def test_bad_scene_is_an_error_not_a_fault(scene_factory):
+    sc = scene_factory("cornell", 64, 48)
+    import copy
+    broken = copy.copy(sc)
+    broken.bvh = sc.bvh.copy()
+    inner = np.flatnonzero(broken.bvh["isLeaf"] == 0)[0]
+    broken.bvh["son2Id"][inner] = 10 ** 6
+    be = Backend().setup_context(64, 48, 4, 1)
+    with pytest.raises(PtmiError) as e:
+        be.initialize_memory(broken)
+    assert e.value.code == -5
+    broken.bvh = sc.bvh.copy()
+    broken.bvh["son2Id"][inner] = inner  # cycle
+    with pytest.raises(PtmiError):
+        be.initialize_memory(broken)
+    broken = copy.copy(sc)
+    broken.triangulation = sc.triangulation.copy()
+    broken.triangulation["materialWithNegativeNormalIndex"][3] = 99
+    with pytest.raises(PtmiError):
+        be.initialize_memory(broken)
+    with pytest.raises(PtmiError):
+        be.render(0, 1)  # no scene resident
+    be.release()
+
+
+@pytest.mark.parametrize("case", list(cases.CASES))
+def test_vs_reference_kernel_on_gpu(case, scene_factory):
+    """The reference's own Kernel_Main (unmodified source -> gfx950 code object) on the same inputs."""
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+    name, sampler, w, h, d = cases.CASES[case]
+    sc = scene_factory(name, w, h)
+    spp = 16
+    r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, spp)
+    color, count, (dep, bbx, tri), _ = render_scene(sc, w, h, d, spp, sampler=sampler)
+    assert np.array_equal(count, r_count)
+    rms = cases.rms_per_channel(color, count, r_color, r_count)
+    flips = np.abs(dep.astype(np.int64) - r_dep.astype(np.int64)).sum()
+    print(f"{case}: rms vs reference {rms}, depth-histogram L1 distance {flips} of {dep.sum()} paths")
+    assert (rms <= RMS_TOL).all(), f"per-channel RMS {rms} > {RMS_TOL}"
+    assert flips <= 2e-3 * dep.sum()
