@@ -1,7 +1,7 @@
 // ptmi_device.hpp - device-side building blocks of the integrator (gfx950).
 //
 // Numerics contract (DESIGN.md "Numerics"): every fp32 operation here is one
-// correctly rounded IEEE-754 +,-,*,/ or sqrt in a fixed association order,
+// correctly rounded IEEE-754 +,-,*,/, sqrt or explicit fma in a fixed order,
 // compiled with -ffp-contract=off, so that a CPU evaluation of the same formulas
 // gives the same bits.  The formulas are those of the reference kernel; each
 // function cites the reference lines whose result it must reproduce.  OpenCL
@@ -33,13 +33,20 @@ __device__ __forceinline__ V4 operator*(V4 a, float s) { return V4{a.x * s, a.y 
 __device__ __forceinline__ V4 operator/(V4 a, float s) { return V4{a.x / s, a.y / s, a.z / s, a.w / s}; }
 __device__ __forceinline__ V4 operator-(V4 a) { return V4{-a.x, -a.y, -a.z, -a.w}; }
 
-// OpenCL dot(float4,float4); association fixed as ((x+y)+z)+w
-__device__ __forceinline__ float dot(V4 a, V4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+// The OpenCL geometric builtins, fixed to the definitions of the OpenCL library the reference meets on
+// this hardware (ROCm device libs, opencl.bc), as far as they are exactly reproducible off the GPU:
+// dot and cross are its FMA chains verbatim; normalize scales by 1/sqrt(dot) where the library scales by
+// v_rsq_f32(dot) (a 1-ulp hardware approximation no CPU checker could follow).  DESIGN.md "Numerics".
+__device__ __forceinline__ float dot(V4 a, V4 b)
+{
+    return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
 __device__ __forceinline__ float length(V4 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ V4 normalize(V4 a) { return a / length(a); }
+__device__ __forceinline__ V4 normalize(V4 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 __device__ __forceinline__ V4 cross(V4 a, V4 b)
 {
-    return V4{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f};
+    return V4{__builtin_fmaf(a.y, b.z, b.y * -a.z), __builtin_fmaf(a.z, b.x, b.z * -a.x),
+              __builtin_fmaf(a.x, b.y, b.x * -a.y), 0.0f};
 }
 
 constexpr float kPi = 3.14159265f;              // PATH_PI, header.cl:10

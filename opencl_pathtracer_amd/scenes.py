@@ -252,7 +252,7 @@ def cornell_box(width, height):
 
     tris = _concat_tris(parts)
     assert len(tris) == 32
-    lights = np.array([light_point((278.0, 279.5, 540.0), power=250000.0)], dtype=S.Light)
+    lights = np.array([light_point((278.0, 279.5, 420.0), power=120000.0)], dtype=S.Light)
     sky, texels = no_sky()
     span = 0.75
     pos, d, r, u = camera((278.0, -800.0, 273.0), (0, 1, 0), (span, 0, 0), (0, 0, span * height / width))

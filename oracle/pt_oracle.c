@@ -33,15 +33,20 @@ static inline f4 scale4(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a
 static inline f4 div4s(f4 a, float s) { return mk4(a.x / s, a.y / s, a.z / s, a.w / s); }
 static inline f4 neg4(f4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
 
-/* dot(float4,float4): 4-component; association order fixed as ((x+y)+z)+w */
-static inline float dot4(f4 a, f4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
-/* length = sqrt(dot); normalize = true division of every component */
+/* The OpenCL geometric builtins are implementation-defined in their last bits.  They are fixed here to
+ * the definitions of the OpenCL library the reference meets on this hardware (ROCm device libs, opencl.bc:
+ * _Z3dotDv4_fS_, _Z5crossDv4_fS_, _Z9normalizeDv4_f), as far as a CPU can evaluate them exactly:
+ *   dot(a,b)     = fma(a.w,b.w, fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)))           -- exact restatement
+ *   cross(a,b).x = fma(a.y,b.z, b.y*(-a.z)) (y, z cyclic), w = 0                -- exact restatement
+ *   length(a)    = sqrt(dot(a,a))                (library: same, with a 3-ulp sqrt)
+ *   normalize(a) = a * (1/sqrt(dot(a,a)))        (library: a * v_rsq_f32(dot), a 1-ulp hardware approximation)
+ * fmaf() is the correctly rounded fused multiply-add (one rounding), whatever -ffp-contract says. */
+static inline float dot4(f4 a, f4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
 static inline float length4(f4 a) { return sqrtf(dot4(a, a)); }
-static inline f4 normalize4(f4 a) { return div4s(a, length4(a)); }
-/* cross(float4,float4): xyz cross, w = 0 (OpenCL 1.2 6.12.5) */
+static inline f4 normalize4(f4 a) { return scale4(a, 1.0f / sqrtf(dot4(a, a))); }
 static inline f4 cross4(f4 a, f4 b)
 {
-    return mk4(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f);
+    return mk4(fmaf(a.y, b.z, b.y * -a.z), fmaf(a.z, b.x, b.z * -a.x), fmaf(a.x, b.y, b.x * -a.y), 0.0f);
 }
 /* OpenCL max(float,float): "y if x < y, otherwise x" */
 static inline float cl_max(float x, float y) { return x < y ? y : x; }
@@ -786,7 +791,13 @@ static void* worker_main(void* p)
 void pto_render(const pto_scene* sc, uint32_t first, uint32_t n, const pto_buffers* out, int n_threads,
                 pto_totals* totals)
 {
-    const uint32_t H = sc->image_height, W = sc->image_width, D = sc->ray_max_depth;
+    pto_render_rows(sc, first, n, 0, sc->image_height, out, n_threads, totals);
+}
+
+void pto_render_rows(const pto_scene* sc, uint32_t first, uint32_t n, uint32_t row0, uint32_t row1,
+                     const pto_buffers* out, int n_threads, pto_totals* totals)
+{
+    const uint32_t H = row1 - row0, W = sc->image_width, D = sc->ray_max_depth;
     pto_totals tt;
     memset(&tt, 0, sizeof tt);
 
@@ -794,7 +805,7 @@ void pto_render(const pto_scene* sc, uint32_t first, uint32_t n, const pto_buffe
         /* the reference's order: one full image per iteration (OpenCL.cpp:76-107) */
         uint32_t it, x, y;
         for (it = first; it < first + n; it++)
-            for (y = 0; y < H; y++)
+            for (y = row0; y < row1; y++)
                 for (x = 0; x < W; x++) pto_kernel_main(sc, x, y, it, out, &tt);
     } else {
         worker_t* ws;
@@ -806,8 +817,8 @@ void pto_render(const pto_scene* sc, uint32_t first, uint32_t n, const pto_buffe
         for (i = 0; i < n_threads; i++) {
             worker_t* w = &ws[i];
             w->sc = sc; w->first = first; w->n = n;
-            w->y0 = (uint32_t)((uint64_t)H * (uint64_t)i / (uint64_t)n_threads);
-            w->y1 = (uint32_t)((uint64_t)H * (uint64_t)(i + 1) / (uint64_t)n_threads);
+            w->y0 = row0 + (uint32_t)((uint64_t)H * (uint64_t)i / (uint64_t)n_threads);
+            w->y1 = row0 + (uint32_t)((uint64_t)H * (uint64_t)(i + 1) / (uint64_t)n_threads);
             w->out = *out;
             w->out.ray_depths = (uint32_t*)calloc(D + 1, 4);
             w->out.ray_intersected_bbx = (uint32_t*)calloc(PTMI_MAX_INTERSECTION_NUMBER, 4);

@@ -75,6 +75,10 @@ typedef struct pto_totals {
 void pto_render(const pto_scene* scene, uint32_t first_iteration, uint32_t n_iterations,
                 const pto_buffers* out, int n_threads, pto_totals* totals);
 
+/* Same for image rows [row0, row1) only (bounded CPU-baseline samples of a large image). */
+void pto_render_rows(const pto_scene* scene, uint32_t first_iteration, uint32_t n_iterations, uint32_t row0,
+                     uint32_t row1, const pto_buffers* out, int n_threads, pto_totals* totals);
+
 /* One work-item: returns 0 if the super-sampling criterion skipped it. */
 int pto_kernel_main(const pto_scene* scene, uint32_t gid_x, uint32_t gid_y, uint32_t iteration,
                     const pto_buffers* out, pto_totals* totals);

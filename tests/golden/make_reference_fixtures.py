@@ -51,6 +51,12 @@ def main(out_dir):
             out[tag + "_bbx_idx"], out[tag + "_bbx_val"] = nzb.astype(np.uint16), bbx[nzb]
             out[tag + "_tri_idx"], out[tag + "_tri_val"] = nzt.astype(np.uint16), tri[nzt]
             print(f"{case} [{first},{first + n}): {ms:.1f} ms, depths {dep.tolist()}", flush=True)
+        if O.have_ref_kernel(case, strict=True):  # the reference's distance to itself (strict vs default build)
+            s_color, s_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, 16, strict=True)
+            d_color = out["it0_8_color"] + out["it8_8_color"]
+            out["noise_floor_rms_16spp"] = cases.rms_per_channel(s_color, s_count, d_color, s_count)
+        one, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1)
+        out["it0_1_color"] = one
         np.savez_compressed(os.path.join(out_dir, f"ref_{case}.npz"), **out)
 
 

@@ -191,12 +191,12 @@ class RefGpuJob(C.Structure):
                 ("ray_bbx", C.c_void_p), ("ray_tri", C.c_void_p), ("kernel_ms", C.c_double)]
 
 
-def ref_kernel_path(config_name):
-    return os.path.join(REF_DIR, f"ref_kernel_{config_name}.hsaco")
+def ref_kernel_path(config_name, strict=False):
+    return os.path.join(REF_DIR, f"ref_kernel_{config_name}{'.strict' if strict else ''}.hsaco")
 
 
-def have_ref_kernel(config_name):
-    return os.path.exists(REF_GPU_LIB) and os.path.exists(ref_kernel_path(config_name))
+def have_ref_kernel(config_name, strict=False):
+    return os.path.exists(REF_GPU_LIB) and os.path.exists(ref_kernel_path(config_name, strict))
 
 
 def _local_size(n):
@@ -205,8 +205,9 @@ def _local_size(n):
             return c
 
 
-def ref_gpu_render(config_name, scene, width, height, ray_max_depth, n_iterations, first_iteration=0):
+def ref_gpu_render(config_name, scene, width, height, ray_max_depth, n_iterations, first_iteration=0, strict=False):
     """Runs the REFERENCE kernel (code object built from its unmodified source) on the GPU.
+    strict=False: OpenCL default arithmetic; strict=True: the -ffp-contract=off / correctly-rounded build.
     Returns (imageColor, imageRayNb, (depths, bbx, tri), kernel_ms)."""
     lib = C.CDLL(REF_GPU_LIB)
     lib.ref_gpu_run.argtypes = [C.POINTER(RefGpuJob)]
@@ -219,7 +220,7 @@ def ref_gpu_render(config_name, scene, width, height, ray_max_depth, n_iteration
     bbx = np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32)
     tri = np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32)
     j = RefGpuJob()
-    j.hsaco_path = ref_kernel_path(config_name).encode()
+    j.hsaco_path = ref_kernel_path(config_name, strict).encode()
     j.width, j.height, j.ray_max_depth = width, height, ray_max_depth
     j.local_x, j.local_y = _local_size(width), _local_size(height)
     j.first_iteration, j.n_iterations = first_iteration, n_iterations

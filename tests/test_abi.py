@@ -1,0 +1,100 @@
+"""The C-ABI library: loads without a GPU, exports exactly what include/ptmi.h declares, and refuses to
+compute without a device (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from opencl_pathtracer_amd import backend, structs as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ptmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptmi_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_agree():
+    assert declared_symbols() == sorted(backend.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = backend.load_library()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"libptmi.so does not export {name}"
+    out = subprocess.run(["nm", "-D", "--defined-only", backend.library_path()], capture_output=True, text=True,
+                         check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "ptmi_" in l and "_Z" not in l}
+    assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
+    assert lib.ptmi_abi_version() == 1
+
+
+def test_headers_compile_as_c_and_cpp(tmp_path):
+    """The static assertions of ptmi_scene.h pin every struct size/offset of the scene contract."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "ptmi.h"\n#include "ptmi_detmath.h"\nint main(void){return sizeof(ptmi_triangle)==336?0:1;}\n')
+    for cc, std in (("gcc", "-std=c11"), ("g++", "-std=c++11")):
+        exe = tmp_path / ("a_" + cc)
+        subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+        assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_numpy_dtypes_match_the_header():
+    sizes = dict(BoundingBox=64, Light=64, Material=48, Node=160, Texture=12, Triangle=336, Sky=92)
+    for name, size in sizes.items():
+        assert getattr(S, name).itemsize == size
+    assert S.Triangle.fields["N"][1] == 192 and S.Triangle.fields["AABB"][1] == 256
+    assert S.Triangle.fields["materialWithPositiveNormalIndex"][1] == 320
+    assert S.Node.fields["son1Id"][1] == 140 and S.Node.fields["isLeaf"][1] == 152
+    assert S.Material.fields["opacity"][1] == 24 and S.Material.fields["isSimpleColor"][1] == 36
+    assert C.sizeof(backend.Config) == 36 and C.sizeof(backend.Counters) == 48
+
+
+def test_argument_validation_needs_no_gpu(built):
+    lib = backend.load_library()
+    ctx = C.c_void_p(None)
+    assert lib.ptmi_setup_context(C.byref(ctx), None) == -1
+    bad = backend.Config(4, 0, 8, 8, 1, 0, 0, 0, 0)  # wrong struct_size
+    assert lib.ptmi_setup_context(C.byref(ctx), C.byref(bad)) == -1 and not ctx.value
+    assert b"struct_size" in lib.ptmi_last_error(None)
+    cfg = backend.Config(C.sizeof(backend.Config), 0, 0, 8, 1, 0, 0, 0, 0)  # zero width
+    assert lib.ptmi_setup_context(C.byref(ctx), C.byref(cfg)) == -1
+    cfg = backend.Config(C.sizeof(backend.Config), 0, 8, 8, 1, 30, 0, 0, 0)  # 30 lights: reference guard
+    assert lib.ptmi_setup_context(C.byref(ctx), C.byref(cfg)) == -4
+    cfg = backend.Config(C.sizeof(backend.Config), 0, 8, 8, 1, 0, 7, 0, 0)  # unknown sampler
+    assert lib.ptmi_setup_context(C.byref(ctx), C.byref(cfg)) == -1
+    assert lib.ptmi_render(None, 0, 1) == -1
+    lib.ptmi_release(None)  # harmless
+
+
+def test_no_device_means_error_not_fallback(built):
+    """On a box without a GPU the product must fail loudly (PTMI_ERR_NO_DEVICE), never compute on the CPU."""
+    lib = backend.load_library()
+    if lib.ptmi_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(backend.PtmiError) as e:
+        backend.Backend().setup_context(8, 8, 1, 0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing shipped may include / import / load / link anything under oracle/ (comments may cite it)."""
+    pkg = os.path.join(ROOT, "opencl_pathtracer_amd")
+    inc = re.compile(r'#\s*include\s*["<][^">]*(oracle|pt_oracle)')
+    imp = re.compile(r'^\s*(from|import)\s+\S*(oracle)', re.M)
+    for base in (pkg, os.path.join(ROOT, "include")):
+        for d, _, files in os.walk(base):
+            for f in files:
+                if not f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                    continue
+                text = open(os.path.join(d, f), errors="ignore").read()
+                assert not inc.search(text) and not imp.search(text), f
+                assert "libpt_oracle" not in text and "oracle_ffi" not in text and "_ref/lib" not in text.replace(
+                    "oracle/_ref/libref_bvh.so)", ""), f
+    out = subprocess.run(["ldd", backend.library_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out

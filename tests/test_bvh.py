@@ -1,0 +1,151 @@
+"""The product BVH builder (ptmi_bvh_create) against the reference's own BVH_Create.
+
+* where oracle/_ref/libref_bvh.so exists (the reference's PathTracer_BVH.cpp compiled UNMODIFIED) every
+  field the reference writes must be equal, and the triangle array must be reordered identically;
+* everywhere: committed digests of trees that were checked against the reference when they were made
+  (tests/golden/bvh_digests.json, generator: this file run as a script).
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]
+import oracle_ffi as O
+from opencl_pathtracer_amd import scenes, bvh_create, structs as S, PtmiError
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bvh_digests.json")
+NODE_FIELDS = ["cutAxis", "triangleStartIndex", "nbTriangles", "son1Id", "son2Id", "isLeaf"]
+CASES = [("cornell", 64, 48), ("matmix", 96, 96), ("tris20k", 96, 64), ("tris1m", 160, 90)]
+
+
+def digest(sc):
+    h = hashlib.sha256()
+    for f in NODE_FIELDS:
+        h.update(np.ascontiguousarray(sc.bvh[f]).tobytes())
+    for bb in ("trianglesAABB", "centroidsAABB"):
+        for f in ("pMin", "pMax", "centroid", "isEmpty"):
+            h.update(np.ascontiguousarray(sc.bvh[bb][f]).tobytes())
+    leaf = sc.bvh["isLeaf"] != 0
+    h.update(np.ascontiguousarray(sc.bvh["comments"][leaf]).tobytes())
+    h.update(np.ascontiguousarray(sc.triangulation["id"]).tobytes())
+    return {"nodes": int(len(sc.bvh)), "max_depth": int(sc.bvhMaxDepth), "leaves": int(leaf.sum()),
+            "sha256": h.hexdigest()}
+
+
+def assert_same_tree(ref_nodes, ref_tris, ref_depth, sc):
+    assert len(ref_nodes) == len(sc.bvh) and ref_depth == sc.bvhMaxDepth
+    for f in NODE_FIELDS:
+        assert np.array_equal(ref_nodes[f], sc.bvh[f]), f
+    for bb in ("trianglesAABB", "centroidsAABB"):
+        for f in ("pMin", "pMax", "centroid", "isEmpty"):
+            assert np.array_equal(ref_nodes[bb][f], sc.bvh[bb][f]), (bb, f)
+    leaf = ref_nodes["isLeaf"] != 0
+    assert np.array_equal(ref_nodes["comments"][leaf], sc.bvh["comments"][leaf])
+    for f in S.Triangle.names:  # field-wise: the reference's member-wise swap does not move padding bytes
+        a, b = ref_tris[f], sc.triangulation[f]
+        if a.dtype.names:
+            for g in a.dtype.names:
+                assert np.array_equal(a[g], b[g]), (f, g)
+        else:
+            assert np.array_equal(a, b), f
+
+
+@pytest.mark.parametrize("name,w,h", CASES)
+def test_matches_reference_builder(name, w, h, built):
+    if not O.have_ref_bvh():
+        pytest.skip("oracle/_ref/libref_bvh.so not present")
+    if name == "tris1m" and os.environ.get("PTMI_SKIP_SLOW"):
+        pytest.skip("slow")
+    sc = scenes.build(name, w, h)
+    ref_nodes, ref_tris, ref_depth = O.ref_bvh_create(sc.triangulation)
+    bvh_create(sc)
+    assert_same_tree(ref_nodes, ref_tris, ref_depth, sc)
+
+
+@pytest.mark.parametrize("name,w,h", CASES)
+def test_matches_committed_digest(name, w, h, built):
+    golden = json.load(open(GOLDEN))
+    sc = bvh_create(scenes.build(name, w, h))
+    assert digest(sc) == golden[name]
+
+
+def _random_soup(n, seed, spread=1.0):
+    rs = np.random.RandomState(seed)
+    c = rs.uniform(-spread, spread, (n, 1, 3))
+    v = (c + rs.uniform(-0.2, 0.2, (n, 3, 3))).astype(np.float32)
+    return scenes.triangle_create(v[:, 0], v[:, 1], v[:, 2])
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 9, 33, 257])
+def test_small_and_ragged_sizes(n, built):
+    tris = _random_soup(n, 100 + n)
+    sc = scenes.cornell_box(8, 8)
+    sc.triangulation = tris
+    bvh_create(sc)
+    assert sc.bvh["isLeaf"][0] == (1 if n <= 4 else 0) or n > 4
+    leaves = sc.bvh[sc.bvh["isLeaf"] != 0]
+    assert leaves["nbTriangles"].sum() == n  # every triangle in exactly one leaf
+    covered = np.zeros(n, bool)
+    for l in leaves:
+        covered[l["triangleStartIndex"]:l["triangleStartIndex"] + l["nbTriangles"]] = True
+    assert covered.all() and sorted(sc.triangulation["id"].tolist()) == list(range(n))
+    if O.have_ref_bvh():
+        ref_nodes, ref_tris, ref_depth = O.ref_bvh_create(tris)
+        assert_same_tree(ref_nodes, ref_tris, ref_depth, sc)
+
+
+def test_coincident_centroids_stop_on_min_diagonal(built):
+    """All centroids (nearly) equal: the reference stops with NODE_LEAF_MIN_DIAG and a big leaf (BVH.cpp:142-149)."""
+    rs = np.random.RandomState(7)
+    base = rs.uniform(-0.2, 0.2, (1, 3, 3)).astype(np.float32)
+    v = np.repeat(base, 40, axis=0)
+    tris = scenes.triangle_create(v[:, 0], v[:, 1], v[:, 2])
+    sc = scenes.cornell_box(8, 8)
+    sc.triangulation = tris
+    bvh_create(sc)
+    assert len(sc.bvh) == 1 and sc.bvh["isLeaf"][0] and sc.bvh["nbTriangles"][0] == 40
+    assert sc.bvh["comments"][0] == S.NODE_LEAF_MIN_DIAG
+    if O.have_ref_bvh():
+        assert_same_tree(*O.ref_bvh_create(tris), sc)
+
+
+def test_empty_triangulation_is_an_error(built):
+    sc = scenes.cornell_box(8, 8)
+    sc.triangulation = np.zeros(0, S.Triangle)
+    with pytest.raises(PtmiError):
+        bvh_create(sc)
+
+
+def test_tree_invariants_1m(built):
+    """Properties the traversal relies on, at the BASELINE size: pre-order numbering (son1 = parent+1),
+    children boxes inside the parent box, depth below the 30-entry stack."""
+    sc = bvh_create(scenes.build("tris1m", 160, 90))
+    b = sc.bvh
+    inner = np.flatnonzero(b["isLeaf"] == 0)
+    assert np.array_equal(b["son1Id"][inner], inner + 1)
+    assert (b["son2Id"][inner] > b["son1Id"][inner]).all() and b["son2Id"].max() < len(b)
+    assert sc.bvhMaxDepth < S.BVH_MAX_DEPTH and len(b) == 665533 and sc.bvhMaxDepth == 22
+    for son in ("son1Id", "son2Id"):
+        child = b["trianglesAABB"][b[son][inner]]
+        parent = b["trianglesAABB"][inner]
+        assert (child["pMin"][:, :3] >= parent["pMin"][:, :3]).all() and (child["pMax"][:, :3] <= parent["pMax"][:, :3]).all()
+    leaves = b[b["isLeaf"] != 0]
+    assert leaves["nbTriangles"].sum() == 1000000 and leaves["nbTriangles"].max() <= 4
+
+
+if __name__ == "__main__":  # regenerate the digests (only meaningful where the reference builder agrees)
+    out = {}
+    for name, w, h in CASES:
+        sc = scenes.build(name, w, h)
+        if O.have_ref_bvh():
+            ref = O.ref_bvh_create(sc.triangulation)
+        bvh_create(sc)
+        if O.have_ref_bvh():
+            assert_same_tree(*ref, sc)
+        out[name] = digest(sc)
+        print(name, out[name])
+    json.dump(out, open(GOLDEN, "w"), indent=1, sort_keys=True)

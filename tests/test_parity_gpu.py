@@ -139,17 +139,54 @@ def test_bad_scene_is_an_error_not_a_fault(scene_factory):
 
 @pytest.mark.parametrize("case", list(cases.CASES))
 def test_vs_reference_kernel_on_gpu(case, scene_factory):
-    """The reference's own Kernel_Main (unmodified source -> gfx950 code object) on the same inputs."""
+    """The reference's own Kernel_Main (unmodified source -> gfx950 code object) on the same inputs.
+
+    OpenCL leaves dot/normalize/sin/cos, FMA contraction and divide/sqrt accuracy to the implementation (AMD's
+    normalize() is p * v_rsq_f32(dot), a hardware approximation), and the integrator is chaotic at a few
+    decisions (shadow rays without epsilon at grazing incidence, hits on edges): no other implementation can
+    match one build of the reference bit for bit.  So the check is statistical, calibrated on the reference's
+    distance to ITSELF (its strict-IEEE build vs its default build):
+      * path statistics: depth histogram within 1e-3 of the paths;
+      * per sample (1 spp): <= 1 % of the samples take another branch, the rest agree to rounding, no bias;
+      * image at 64 spp: RMS <= max(1e-4, 3 x RMS(reference default vs reference strict))."""
     if not O.have_ref_kernel(case):
         pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
-    spp = 16
-    r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, spp)
-    color, count, (dep, bbx, tri), _ = render_scene(sc, w, h, d, spp, sampler=sampler)
+
+    r1, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1)
+    g1, _, _, _ = render_scene(sc, w, h, d, 1, sampler=sampler)
+    agree = cases.sample_agreement(g1, r1)
+    assert agree["flip_fraction"] <= cases.MAX_FLIP_FRACTION and agree["median_rel"] <= 1e-6, agree
+
+    spp = 64
+    r_color, r_count, (r_dep, _, _), _ = O.ref_gpu_render(case, sc, w, h, d, spp)
+    color, count, (dep, _, _), _ = render_scene(sc, w, h, d, spp, sampler=sampler)
     assert np.array_equal(count, r_count)
-    rms = cases.rms_per_channel(color, count, r_color, r_count)
+    rms = cases.rms_per_channel(color, count, r_color, r_count).max()
+    floor = None
+    if O.have_ref_kernel(case, strict=True):
+        s_color, s_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, spp, strict=True)
+        floor = cases.rms_per_channel(s_color, s_count, r_color, r_count).max()
     flips = np.abs(dep.astype(np.int64) - r_dep.astype(np.int64)).sum()
-    print(f"{case}: rms vs reference {rms}, depth-histogram L1 distance {flips} of {dep.sum()} paths")
-    assert (rms <= RMS_TOL).all(), f"per-channel RMS {rms} > {RMS_TOL}"
-    assert flips <= 2e-3 * dep.sum()
+    mean_rel = abs(float(color[..., :3].mean()) - float(r_color[..., :3].mean())) / float(r_color[..., :3].mean())
+    print(f"{case}: 1-spp agreement {agree}; {spp} spp: rms vs reference {rms:.3e}, reference strict-vs-default "
+          f"{floor if floor is None else format(floor, '.3e')}, depth-histogram L1 {flips}/{dep.sum()}, mean rel diff {mean_rel:.2e}")
+    assert flips <= 1e-3 * dep.sum()
+    assert mean_rel <= 2e-4
+    assert rms <= max(RMS_TOL, 3 * (floor or 0.0)), (rms, floor)
+
+
+def test_north_star_rms_at_config_spp(scene_factory):
+    """BASELINE config 2 quotes the Cornell box at 1024 spp: there the chaotic samples average out and the
+    image meets the north-star bound against the reference's default build."""
+    case = "cornell_64x48_d4"
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present")
+    name, sampler, w, h, d = cases.CASES[case]
+    sc = scene_factory(name, w, h)
+    r_color, r_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1024)
+    color, count, _, _ = render_scene(sc, w, h, d, 1024)
+    rms = cases.rms_per_channel(color, count, r_color, r_count)
+    print(f"{case} at 1024 spp: per-channel rms vs reference {rms}")
+    assert (rms <= RMS_TOL).all(), rms
