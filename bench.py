@@ -162,12 +162,11 @@ def cpu_baseline(scene, W, H, D, rows):
     on a bounded sample of the SAME workload: iteration 0 of the first `rows` image rows, all host threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     if rows <= 0:
         # ~0.014 Mpaths/s/thread on this scene (BASELINE.md): aim at ~15 s
         rows = max(cores, min(H, int(15 * 0.014e6 * cores / W)))
         rows = (rows // cores) * cores or cores
-    sub = __import__("copy").copy(scene)
     # same camera, same pixels: the sample renders rows [0, rows) of the full-size image
     t0 = time.perf_counter()
     _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores)
@@ -176,6 +175,18 @@ def cpu_baseline(scene, W, H, D, rows):
             "sample": f"iteration 0 of rows 0..{rows - 1} of the {W}x{H} image ({rows * W} paths, "
                       f"{totals['segments']} segments) in {dt:.1f} s on {cores} threads",
             "Mpaths/s": totals["paths"] / dt / 1e6}
+
+
+def host_cores():
+    """CPU cores this process may really use: the affinity mask, cut down to the cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def oracle_rows(O, scene, W, H, D, rows, threads):

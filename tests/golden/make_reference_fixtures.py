@@ -51,10 +51,16 @@ def main(out_dir):
             out[tag + "_bbx_idx"], out[tag + "_bbx_val"] = nzb.astype(np.uint16), bbx[nzb]
             out[tag + "_tri_idx"], out[tag + "_tri_val"] = nzt.astype(np.uint16), tri[nzt]
             print(f"{case} [{first},{first + n}): {ms:.1f} ms, depths {dep.tolist()}", flush=True)
-        if O.have_ref_kernel(case, strict=True):  # the reference's distance to itself (strict vs default build)
-            s_color, s_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, 16, strict=True)
+        if O.have_ref_kernel(case, strict=True):
+            # second legal build of the same source (-ffp-contract=off, correctly rounded divide/sqrt):
+            # (a) the reference's distance to itself, (b) traversal-work histograms under IEEE arithmetic
+            s_color, s_count, (s_dep, s_bbx, s_tri), _ = O.ref_gpu_render(case, sc, w, h, d, 16, strict=True)
             d_color = out["it0_8_color"] + out["it8_8_color"]
             out["noise_floor_rms_16spp"] = cases.rms_per_channel(s_color, s_count, d_color, s_count)
+            k = np.arange(5000, dtype=np.int64)
+            out["strict_16spp_work"] = np.array([(s_bbx.astype(np.int64) * k).sum(), (s_tri.astype(np.int64) * k).sum()])
+            out["strict_16spp_depths"] = s_dep
+            out["strict_16spp_color_mean"] = s_color[..., :3].mean(axis=(0, 1))
         one, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1)
         out["it0_1_color"] = one
         np.savez_compressed(os.path.join(out_dir, f"ref_{case}.npz"), **out)

@@ -132,20 +132,25 @@ def test_bounding_box_quirks(built):
         return lib.pto_bounding_box_intersects(box.ctypes.data_as(C.c_void_p), _arr4(o), _arr4(d), f32(lim))
 
     b = _box((1, -1, -1), (2, 1, 1))
-    assert hit(b, (0, 0, 0, 1), (1, 0, 0, 0), np.inf) == 1
-    assert hit(b, (0, 0, 0, 1), (-1, 0, 0, 0), np.inf) == 0  # behind
-    assert hit(b, (0, 3, 0, 1), (1, 0, 0, 0), np.inf) == 0   # misses in y
-    assert hit(b, (1.5, 0, 0, 1), (0, 1, 0, 0), 0.0) == 1    # origin inside: true whatever the limit (cl:132)
-    assert hit(_box((1, -1, -1), (2, 1, 1), empty=1), (0, 0, 0, 1), (1, 0, 0, 0), np.inf) == 0
+    D = (1, 1e-3, 1e-3, 0)  # slightly off axis, see the +0 quirk below
+    assert hit(b, (0, 0, 0, 1), D, np.inf) == 1
+    assert hit(b, (0, 0, 0, 1), (-1, 1e-3, 1e-3, 0), np.inf) == 0  # behind
+    assert hit(b, (0, 3, 0, 1), D, np.inf) == 0   # misses in y
+    assert hit(b, (1.5, 0, 0, 1), (1e-3, 1, 1e-3, 0), 0.0) == 1    # origin inside: true whatever the limit (cl:132)
+    assert hit(_box((1, -1, -1), (2, 1, 1), empty=1), (0, 0, 0, 1), D, np.inf) == 0
     # the cull compares the LINEAR entry distance with the SQUARED hit distance (cl:135):
     # entry t = 1; a current hit at distance 0.9 has squared distance 0.81 -> box culled (correct) ...
-    assert hit(b, (0, 0, 0, 1), (1, 0, 0, 0), 0.81) == 0
+    assert hit(b, (0, 0, 0, 1), D, 0.81) == 0
     # ... but a hit at distance 3 (squared 9) keeps a box entered at t = 5 alive: 5 < 9
     far = _box((5, -1, -1), (6, 1, 1))
-    assert hit(far, (0, 0, 0, 1), (1, 0, 0, 0), 9.0) == 1
+    assert hit(far, (0, 0, 0, 1), D, 9.0) == 1
     # and for distances below 1 a NEARER box is dropped: entry t = 0.5 > 0.6^2 = 0.36
     near = _box((0.5, -1, -1), (0.55, 1, 1))
-    assert hit(near, (0, 0, 0, 1), (1, 0, 0, 0), 0.36) == 0
+    assert hit(near, (0, 0, 0, 1), D, 0.36) == 0
+    # quirk: a direction component that is exactly +0 takes the "else" slab (cl:79-83,93-97) with inverse = +inf:
+    # tyMin = +inf, tyMax = -inf, so "tMin > tyMax" rejects EVERY box; with -0 the slabs come out right
+    assert hit(b, (0, 0, 0, 1), (1, 0.0, 1e-3, 0), np.inf) == 0
+    assert hit(b, (0, 0, 0, 1), (1, -0.0, -0.0, 0), np.inf) == 1
 
 
 def test_triangle_intersection(built):
