@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=10)
+    ap.add_argument("--kernel", choices=["wavefront", "megakernel"], default="wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of iteration 0 the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
@@ -52,7 +53,7 @@ def main():
     import torch
     import torch.distributed as dist
     import opencl_pathtracer_amd as pt
-    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS
+    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS, FLAG_MEGAKERNEL
     from opencl_pathtracer_amd.distributed import FusedAccumulators
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,7 +75,7 @@ def main():
     t_scene = time.time() - t0
 
     be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=local_rank,
-                                    flags=FLAG_NO_HISTOGRAMS)
+                                    flags=FLAG_NO_HISTOGRAMS | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0))
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)
     fb.bind(be)
@@ -143,7 +144,8 @@ def main():
             "segments_per_path": total["segments"] / max(total["paths"], 1),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "render_kernel", "launches": launches,
+                         "kernel": "render_wavefront_kernel" if args.kernel == "wavefront" else "render_kernel",
+                         "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
                          "box_tests_per_path": delta["box_tests"] / max(delta["paths"], 1),
                          "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1)},

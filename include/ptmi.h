@@ -59,6 +59,7 @@ typedef struct ptmi_config {
 } ptmi_config;
 
 #define PTMI_FLAG_NO_HISTOGRAMS 1u /* skip the three per-path histogram atomics (FullKernel.cl:1319-1331); totals are still kept */
+#define PTMI_FLAG_MEGAKERNEL 2u    /* one path per lane (kernels.hip) instead of the persistent wavefront kernel; same results */
 
 /* What OpenCL_InitializeMemory copies with CL_MEM_COPY_HOST_PTR and passes as
  * kernel arguments 1..17 (OpenCL.cpp:165-197).  Arrays are raw dumps of the

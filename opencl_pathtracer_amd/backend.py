@@ -67,6 +67,7 @@ class Counters(C.Structure):
 
 
 FLAG_NO_HISTOGRAMS = 1
+FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",

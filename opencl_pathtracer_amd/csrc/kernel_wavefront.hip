@@ -1,0 +1,354 @@
+// kernel_wavefront.hip - persistent-wavefront path tracer for gfx950 (MI355X).  The default integrator.
+//
+// Why not one work-item = one path like the reference (Kernel_Main, FullKernel.cl:1180): on a 64-wide
+// wavefront a path that ends after one bounce would idle until the slowest of its 63 neighbours has done
+// ten, and closest-hit traversal, shadow traversal and shading would run one after the other under
+// partial exec masks.  Here instead:
+//
+//  * The grid is PERSISTENT: as many workgroups as the chip holds, alive for the whole launch.  Work is
+//    a queue of jobs, job = one pixel x all iterations of the launch, handed out 8x8-tile-wise by one
+//    atomic per wave whenever some of its lanes run dry (`dequeue` in MI355X_MICROARCH.md: the cheapest
+//    cross-CU primitive).  A lane owns its pixel: the radiance sum stays in registers and the framebuffer
+//    is read and written once per job, with no atomics, in iteration order (bit-exact accumulation).
+//  * Every lane is a small STATE MACHINE over the same three step kinds:
+//        I  one inner-node step  (load one 64-byte DNode, two slab tests, push/pop on the LDS stack)
+//        T  one triangle test    (load one 64-byte DTri)
+//        P  path logic           (shade a finished closest-hit query, set up / account a shadow ray,
+//                                 scatter, finish the path, start the next iteration or fetch a new job)
+//    A camera segment and a shadow ray are the same I/T steps with another `limit` and exit rule, so lanes
+//    in either phase, of any bounce, of any pixel, run together.
+//  * Per loop trip the WAVE picks one kind by __ballot / popcount: P when enough lanes wait for it (or
+//    nothing else can run), otherwise the kind more lanes want.  Lanes of the other kinds sit out that
+//    trip; none is ever more than a few trips from running because waiters accumulate.
+//  * Per ray the visit sequence is exactly the reference's (near child first, far child pushed, leaf
+//    triangles in index order, limit updated between tests, FullKernel.cl:620-702): only WHEN a lane
+//    takes its next step changes, never WHICH step it takes.  Results are bit-identical to the
+//    one-path-per-lane kernel (kernels.hip) and to the CPU checker.
+//
+// Exit: a lane dies when the queue is empty and its pixel is flushed; a wave leaves the loop when no lane
+// has work of any kind (every path is bounded by the ray depth, every traversal by the finite tree).
+#include <hip/hip_runtime.h>
+
+#include "ptmi_device.hpp"
+#include "ptmi_shading.hpp"
+
+namespace ptmi_dev {
+
+constexpr int kWfBlock = 256;
+constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
+constexpr int kPostThreshold = 16;  // lanes waiting for path logic before the wave spends a trip on it
+
+__device__ __forceinline__ void decode_leaf(const DScene& sc, uint32_t ref, uint32_t& tri_i, uint32_t& tri_end)
+{
+    uint32_t count = (ref >> REF_COUNT_SHIFT) & 7u;
+    uint32_t start = ref & REF_INDEX_MASK_LEAF;
+    if (count == REF_COUNT_BIG) {
+        const DBigLeaf bl = sc.big_leaves[start];
+        start = bl.start;
+        count = bl.count;
+    }
+    tri_i = start;
+    tri_end = start + count;
+}
+
+__global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene sc, const uint32_t first_iteration,
+                                                                    const uint32_t n_iterations, const uint32_t n_jobs,
+                                                                    uint32_t* __restrict__ job_counter)
+{
+    __shared__ uint32_t stack_mem[kWfStack * kWfBlock];
+    __shared__ unsigned long long block_counters[C_COUNT];
+
+    const uint32_t tid = threadIdx.x;
+    if (tid < C_COUNT) block_counters[tid] = 0;
+    __syncthreads();
+    uint32_t* const stack = &stack_mem[tid];
+    const uint32_t tiles_x = (sc.width + 7u) >> 3;
+    const bool owns_pixel = sc.sampler != PTMI_SAMPLER_RANDOM;
+    const uint32_t it_end = first_iteration + n_iterations;
+
+    // ---- lane state -----------------------------------------------------------------------------
+    bool alive = true;       // may still receive work
+    bool need_path = true;   // no path in flight
+    bool has_pixel = false;
+    uint32_t gx = 0, gy = 0, it = it_end;
+    V4 sum = v4(0, 0, 0, 0);
+    float count = 0;
+    // path
+    int seed = 1;
+    float sample_x = 0, sample_y = 0;
+    V4 transfer = v4(1, 1, 1, 1), radiance = v4(0, 0, 0, 0);
+    uint32_t reflection = 0, p_bbx = 0, p_tri = 0;
+    bool in_water = false;
+    // current query
+    Ray r;
+    r.o = v4(0, 0, 0, 0); r.d = v4(0, 0, 0, 0); r.ix = r.iy = r.iz = 0;
+    float limit = 0;
+    bool shadow = false, found = false;
+    uint32_t cur = REF_NONE, tri_i = 0, tri_end = 0;
+    int top = 0;
+    Hit hit;
+    hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
+    // saved across the shadow rays of one surface hit
+    Surface sf;
+    sf.Ng = sf.Ns = sf.color = v4(0, 0, 0, 0);
+    sf.mat.type = 0; sf.mat.opacity = 0; sf.mat.texture_id = 0; sf.mat.is_simple_color = 1;
+    sf.mat.color[0] = sf.mat.color[1] = sf.mat.color[2] = sf.mat.color[3] = 0;
+    V4 cam_d = v4(0, 0, 0, 0), direct = v4(0, 0, 0, 0);
+    uint32_t light_idx = 0;
+    // totals
+    unsigned long long n_bbx = 0, n_tri = 0;
+    uint32_t n_seg = 0, n_shadow = 0, n_hits = 0, n_paths = 0;
+
+    // statistics + accumulation of a finished path (FullKernel.cl:1319-1345)
+    auto finish_path = [&]() {
+        n_bbx += p_bbx; n_tri += p_tri; n_hits += reflection; n_paths++;
+        if (sc.hist_depths) {
+            atomicAdd(&sc.hist_depths[reflection], 1u);
+            if (p_bbx < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_bbx[p_bbx], 1u);
+            if (p_tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[p_tri], 1u);
+        }
+        if (owns_pixel) {
+            sum = sum + radiance;
+            count = count + 1.f;
+        } else {
+            // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345)
+            const uint32_t off = sample_pixel(sc, sample_x, sample_y);
+            atomicAdd(&sc.image_color[4 * off + 0], radiance.x);
+            atomicAdd(&sc.image_color[4 * off + 1], radiance.y);
+            atomicAdd(&sc.image_color[4 * off + 2], radiance.z);
+            atomicAdd(&sc.image_color[4 * off + 3], radiance.w);
+            atomicAdd(&sc.image_ray_nb[off], 1.f);
+        }
+        it++;
+        need_path = true;
+        cur = REF_NONE; tri_i = tri_end = 0;
+    };
+
+    for (;;) {
+        const bool pending = !need_path && tri_i < tri_end;
+        const bool want_inner = !need_path && !pending && cur != REF_NONE;
+        const bool want_post = alive && (need_path || (!pending && cur == REF_NONE));
+        const unsigned long long m_t = __ballot(pending), m_i = __ballot(want_inner), m_p = __ballot(want_post);
+        if ((m_t | m_i | m_p) == 0ull) break;
+        const int n_t = __popcll(m_t), n_i = __popcll(m_i), n_p = __popcll(m_p);
+
+        if (n_p >= kPostThreshold || (n_t == 0 && n_i == 0)) {
+            // ================================ P: path logic ========================================
+            if (want_post) {
+                bool end_path = false;
+                bool start_shadow = false, do_scatter = false;
+                if (!need_path) {
+                    if (!shadow) {
+                        // closest-hit query finished (FullKernel.cl:1252-1288)
+                        if (found) {
+                            load_surface(sc, r, hit, sf);
+                            cam_d = r.d;
+                            direct = v4(0, 0, 0, 0);
+                            light_idx = 0;
+                            if (sc.n_lights > 0) start_shadow = true;
+                            else do_scatter = true;
+                        } else {
+                            radiance = radiance + (sky_color(sc.sky, sc.texels, r.d) * transfer);
+                            end_path = true;
+                        }
+                    } else {
+                        // shadow query finished (Scene_ComputeDirectIllumination, :944-947)
+                        if (!found) {
+                            const ptmi_light light = sc.lights[light_idx];
+                            const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
+                            direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
+                        }
+                        light_idx++;
+                        if (light_idx < sc.n_lights) start_shadow = true;
+                        else do_scatter = true;
+                    }
+                    if (start_shadow) {
+                        // :932-944: ray from the hit point (no offset) towards light `light_idx`
+                        const ptmi_light light = sc.lights[light_idx];
+                        const bool directional = light.type == PTMI_LIGHT_DIRECTIONNAL;
+                        const V4 full = directional ? -v4(light.direction) : v4(light.position) - hit.point;
+                        r.o = hit.point;
+                        ray_set_direction(r, full);
+                        limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
+                        shadow = true;
+                        found = false;
+                        cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+                        n_shadow++;
+                    }
+                    if (do_scatter) {
+                        r.d = cam_d;
+                        radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
+                        reflection++;
+                        shadow = false;
+                        const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // :1296-1304
+                        const float m = transfer.x < m_yz ? m_yz : transfer.x;
+                        if (m <= kMinContribution || reflection >= sc.max_depth) {
+                            end_path = true;
+                        } else {
+                            limit = INFINITY;
+                            found = false;
+                            cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+                            n_seg++;
+                        }
+                    }
+                    if (end_path) finish_path();
+                }
+
+                // ---- job hand-out: one atomic per wave for all lanes that ran dry -----------------
+                const bool want_job = need_path && it >= it_end;
+                if (want_job && has_pixel) {
+                    if (owns_pixel) {
+                        const uint32_t off = gy * sc.width + gx;
+                        *reinterpret_cast<float4*>(&sc.image_color[4 * off]) = make_float4(sum.x, sum.y, sum.z, sum.w);
+                        sc.image_ray_nb[off] = count;
+                    }
+                    has_pixel = false;
+                }
+                const unsigned long long m_job = __ballot(want_job);
+                if (want_job) {
+                    const int leader = __ffsll((long long)m_job) - 1;
+                    const uint32_t rank = __popcll(m_job & ((1ull << (tid & 63u)) - 1ull));
+                    uint32_t base = 0;
+                    if ((int)(tid & 63u) == leader) base = atomicAdd(job_counter, (uint32_t)__popcll(m_job));
+                    base = __shfl(base, leader);
+                    const uint32_t job = base + rank;
+                    if (job >= n_jobs) {
+                        alive = false;
+                    } else {
+                        const uint32_t tile = job >> 6, in_tile = job & 63u;
+                        gx = (tile % tiles_x) * 8u + (in_tile & 7u);
+                        gy = (tile / tiles_x) * 8u + (in_tile >> 3);
+                        if (gx < sc.width && gy < sc.height) {
+                            has_pixel = true;
+                            it = first_iteration;
+                            if (owns_pixel) {
+                                const uint32_t off = gy * sc.width + gx;
+                                sum = v4(*reinterpret_cast<const float4*>(&sc.image_color[4 * off]));
+                                count = sc.image_ray_nb[off];
+                            }
+                        }  // else: edge tile, pixel outside the image: ask again next time
+                    }
+                }
+
+                // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
+                if (need_path && has_pixel && it < it_end) {
+                    seed = lcg_seed(gx, gy, sc.width, sc.height, it);
+                    draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
+                    r.o = v4(sc.cam_pos);
+                    ray_set_direction(r, (v4(sc.cam_dir) + (v4(sc.cam_right) * sample_x)) + (v4(sc.cam_up) * sample_y));
+                    radiance = v4(0, 0, 0, 0);
+                    transfer = v4(1, 1, 1, 1);
+                    reflection = 0; p_bbx = 0; p_tri = 0;
+                    in_water = false;
+                    shadow = false;
+                    found = false;
+                    need_path = false;
+                    if (sc.max_depth > 0) {
+                        limit = INFINITY;
+                        cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+                        n_seg++;
+                    } else {
+                        finish_path();  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
+                    }
+                }
+            }
+        } else if (n_t >= n_i) {
+            // ================================ T: one triangle test =================================
+            if (pending) {
+                Hit h;
+                p_tri++;
+                if (tri_hit(&sc.tris[tri_i], r, limit, h)) {
+                    found = true;
+                    if (shadow) {  // any hit ends a shadow query (FullKernel.cl:724-727)
+                        tri_end = tri_i;
+                        cur = REF_NONE; top = 0;
+                    } else {
+                        h.tri = tri_i;
+                        hit = h;
+                    }
+                }
+                tri_i++;
+            }
+        } else {
+            // ================================ I: one node step =====================================
+            if (want_inner) {
+                if (cur & REF_LEAF) {
+                    decode_leaf(sc, cur, tri_i, tri_end);
+                    cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
+                } else {
+                    const float4* np = reinterpret_cast<const float4*>(&sc.nodes[cur & REF_INDEX_MASK_INNER]);
+                    const float4 a = np[0], b = np[1], c = np[2], d = np[3];
+                    const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
+                    const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
+                    const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
+                    const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
+                    const bool fwd = da > 0;
+                    const bool h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
+                    const bool h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                    p_bbx += 2;
+                    const uint32_t near_ref = fwd ? ref1 : ref2, far_ref = fwd ? ref2 : ref1;
+                    const bool near_hit = fwd ? h1 : h2, far_hit = fwd ? h2 : h1;
+                    if (near_hit) {
+                        if (far_hit) stack[(top++) * kWfBlock] = far_ref;
+                        cur = near_ref;
+                    } else if (far_hit) {
+                        cur = far_ref;
+                    } else {
+                        cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
+                    }
+                    if (cur != REF_NONE && (cur & REF_LEAF)) {  // reached a leaf: its triangles are next
+                        decode_leaf(sc, cur, tri_i, tri_end);
+                        cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
+                    }
+                }
+            }
+        }
+    }
+
+    atomicAdd(&block_counters[C_PATHS], (unsigned long long)n_paths);
+    atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)n_seg);
+    atomicAdd(&block_counters[C_HITS], (unsigned long long)n_hits);
+    atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
+    atomicAdd(&block_counters[C_BBX], n_bbx);
+    atomicAdd(&block_counters[C_TRI], n_tri);
+    __syncthreads();
+    if (tid < C_COUNT) atomicAdd(&sc.counters[tid], block_counters[tid]);
+}
+
+}  // namespace ptmi_dev
+
+namespace ptmi_internal {
+
+int wavefront_resident_blocks(int device)
+{
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel, ptmi_dev::kWfBlock, 0) != hipSuccess)
+        return 0;
+    if (per_cu < 1) per_cu = 1;
+    return per_cu * prop.multiProcessorCount;
+}
+
+int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
+                            int resident_blocks, void* stream, std::string* err)
+{
+    if (n_iterations == 0) return PTMI_OK;
+    const uint32_t tiles = ((sc.width + 7u) / 8u) * ((sc.height + 7u) / 8u);
+    const uint32_t n_jobs = tiles * 64u;
+    hipError_t e = hipMemsetAsync(job_counter, 0, sizeof(uint32_t), (hipStream_t)stream);
+    if (e == hipSuccess) {
+        uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
+        if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
+        hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel, dim3(blocks), dim3(ptmi_dev::kWfBlock), 0,
+                           (hipStream_t)stream, sc, first_iteration, n_iterations, n_jobs, job_counter);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        if (err) *err = std::string("render_wavefront_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    return PTMI_OK;
+}
+
+}  // namespace ptmi_internal

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ptmi_device.hpp"
+#include "ptmi_shading.hpp"
 
 namespace ptmi_dev {
 
@@ -85,117 +86,6 @@ __device__ __forceinline__ bool traverse(const DScene& sc, const Ray& r, float l
     return found;
 }
 
-struct Surface {
-    V4 Ng, Ns, color;
-    DMat mat;
-};
-
-// What Kernel_Main does between BVH_IntersectRay and the light loop
-// (FullKernel.cl:1254-1274) plus the deferred Triangle_GetColorValueAt (:591-602).
-__device__ __forceinline__ void load_surface(const DScene& sc, const Ray& r, const Hit& hit, Surface& sf)
-{
-    const V4 N = v4(sc.tris[hit.tri].n);
-    const DShade* sh = &sc.shade[hit.tri];
-    const float4* s4 = reinterpret_cast<const float4*>(sh);
-    const V4 N1 = v4(s4[0]), N2 = v4(s4[1]), N3 = v4(s4[2]);
-    const uint32_t mat_id = hit.front ? sh->mat_pos : sh->mat_neg;
-    sf.mat = sc.mats[mat_id];
-
-    const float b = (1 - hit.s) - hit.t;
-    if (sf.mat.is_simple_color) {
-        sf.color = v4(sf.mat.color);
-    } else {
-        const float* uv = hit.front ? sh->uvp : sh->uvn;
-        const float tu = (uv[0] * b + uv[2] * hit.s) + uv[4] * hit.t;
-        const float tv = (uv[1] * b + uv[3] * hit.s) + uv[5] * hit.t;
-        sf.color = texture_pixel(sc.textures[sf.mat.texture_id], sc.texels, tu, tv);
-    }
-
-    const bool same_dir = dot(r.d, N) > 0;                       // :1267
-    sf.Ng = same_dir ? -N : N;                                   // Triangle_GetNormal, header.cl:500
-    V4 Ns = normalize(((N2 * hit.s) + (N3 * hit.t)) + (N1 * b)); // Triangle_GetSmoothNormal, :604-610
-    if (same_dir) Ns = -Ns;
-    Ns = put_in_same_hemisphere(Ns, -r.d);                       // :1273
-    sf.Ns = normalize(Ns);                                       // :1274
-}
-
-// Scene_ComputeRadiance, FullKernel.cl:791-891: updates transfer, the ray and
-// isInWater; returns the radiance gathered at this bounce.
-__device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const Hit& hit, const Surface& sf, V4 direct,
-                                      V4& transfer)
-{
-    V4 N = r.d;
-    V4 radiance = v4(0, 0, 0, 0);
-    V4 out = r.d;
-    const int type = sf.mat.type;
-    if (type == PTMI_MAT_STANDART) {
-        transfer = transfer * sf.color;
-        radiance = direct * transfer;
-        out = cosine_sample_hemisphere(seed, sf.Ns);
-        N = sf.Ns;
-    } else if (type == PTMI_MAT_GLASS) {
-        const float f = fresnel_fraction(1, kNGlass, -dot(r.d, sf.Ns), r.d, sf.Ns, nullptr);
-        if (lcg_random(seed) < f) {
-            out = reflect_about(r.d, sf.Ns);
-            N = sf.Ng;
-        } else {
-            transfer = transfer * (sf.color * (1 - sf.mat.opacity));
-            N = r.d;
-        }
-    } else if (type == PTMI_MAT_WATER) {
-        V4 refracted = v4(0, 0, 0, 0);
-        const float n1 = in_water ? kNWater : 1.f, n2 = in_water ? 1.f : kNWater;
-        const float f = fresnel_fraction(n1, n2, -dot(r.d, sf.Ns), r.d, sf.Ns, &refracted);
-        if (lcg_random(seed) < f) {
-            out = reflect_about(r.d, sf.Ns);
-            N = sf.Ng;
-        } else {
-            in_water = !in_water;
-            out = refracted;
-            N = -sf.Ng;
-            transfer = transfer * ((n2 * n2) / (n1 * n1));
-        }
-    } else if (type == PTMI_MAT_VARNHISHED) {
-        radiance = radiance + ((direct * sf.color) * transfer);
-        const float f1 = fresnel_varnish(r.d, sf.Ns);
-        if (lcg_random(seed) < f1) {
-            out = reflect_about(r.d, sf.Ns);
-        } else {
-            out = cosine_sample_hemisphere(seed, sf.Ns);
-            transfer = transfer * sf.color;
-        }
-    }
-    out = put_in_same_hemisphere(out, N);
-    ray_set_direction(r, out);
-    r.o = hit.point + out * 0.001f;  // :880 uses the un-normalised direction
-    return radiance;
-}
-
-// sampler(), FullKernel.cl:1119-1150
-__device__ __forceinline__ void draw_sample(const DScene& sc, uint32_t gx, uint32_t gy, uint32_t iteration, int& seed,
-                                            float& sx, float& sy)
-{
-    if (sc.sampler == PTMI_SAMPLER_UNIFORM) {
-        const int sample_id = (int)(iteration % 9u);
-        sx = (float)gx; sy = (float)gy;
-        float ox = (float)(sample_id % 3), oy = (float)(sample_id / 3);
-        ox += 0.5f; oy += 0.5f;
-        ox /= 3.f; oy /= 3.f;
-        sx += ox; sy += oy;
-        sx /= (float)sc.width; sy /= (float)sc.height;
-        sx -= 0.5f; sy -= 0.5f;
-    } else if (sc.sampler == PTMI_SAMPLER_RANDOM) {
-        sx = lcg_random(seed);
-        sy = lcg_random(seed);
-        sx *= 0.9f; sy *= 0.9f;
-        sx += 0.05f; sy += 0.05f;
-        sx -= 0.5f; sy -= 0.5f;
-    } else {
-        sx = (((float)gx + 0.9f * lcg_random(seed)) + 0.05f) / (float)sc.width - 0.5f;
-        sy = (((float)gy + 0.9f * lcg_random(seed)) + 0.05f) / (float)sc.height - 0.5f;
-    }
-}
-
 // One path = one Kernel_Main work-item (FullKernel.cl:1180-1331) up to the
 // statistics; returns the radiance and the sample position.
 __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t gy, uint32_t iteration,
@@ -254,16 +144,6 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
     }
     depth = reflection;
     return radiance;
-}
-
-// pixel a sample lands on, FullKernel.cl:1333-1336 (double arithmetic)
-__device__ __forceinline__ uint32_t sample_pixel(const DScene& sc, float sx, float sy)
-{
-    int px = (int)(((double)sx + 0.5) * (int)sc.width);
-    int py = (int)(((double)sy + 0.5) * (int)sc.height);
-    px = min(px, (int)sc.width - 1);
-    py = min(py, (int)sc.height - 1);
-    return (uint32_t)py * sc.width + (uint32_t)px;
 }
 
 __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const uint32_t first_iteration,

@@ -44,6 +44,8 @@ struct ptmi_ctx {
     bool accum_bound = false;  // caller-owned accumulators
     uint32_t* d_hist = nullptr;  // depths | bbx | tri
     unsigned long long* d_counters = nullptr;
+    uint32_t* d_job_counter = nullptr;
+    int resident_blocks = 0;
     DScene ds{};
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -75,6 +77,7 @@ void free_scene_memory(ptmi_ctx* ctx)
     ctx->d_color = ctx->d_count = nullptr;
     ctx->d_hist = nullptr;
     ctx->d_counters = nullptr;
+    ctx->d_job_counter = nullptr;
     ctx->accum_bound = false;
     ctx->have_scene = false;
 }
@@ -288,6 +291,7 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
         return fail(nullptr, PTMI_ERR_HIP, msg);
     }
     ctx->stream = ctx->own_stream;
+    ctx->resident_blocks = wavefront_resident_blocks(ctx->device);
     *out = ctx;
     return PTMI_OK;
 }
@@ -336,9 +340,10 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     HIP_TRY(ctx, hipMalloc(&dc, npix * 16)); ctx->allocations.push_back(dc);
     HIP_TRY(ctx, hipMalloc(&dn, npix * 4));  ctx->allocations.push_back(dn);
     HIP_TRY(ctx, hipMalloc(&dh, hist_words * 4)); ctx->allocations.push_back(dh);
-    HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8)); ctx->allocations.push_back(dk);
+    HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8 + 64)); ctx->allocations.push_back(dk);
     ctx->d_color = (float*)dc; ctx->d_count = (float*)dn; ctx->d_hist = (uint32_t*)dh;
     ctx->d_counters = (unsigned long long*)dk;
+    ctx->d_job_counter = (uint32_t*)((char*)dk + C_COUNT * 8);
 
     ds.image_color = ctx->d_color;
     ds.image_ray_nb = ctx->d_count;
@@ -399,7 +404,10 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
     }
     HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
     std::string err;
-    const int rc = launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err);
+    const int rc = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL)
+                       ? launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err)
+                       : launch_render_wavefront(ctx->ds, first_iteration, n_iterations, ctx->d_job_counter,
+                                                 ctx->resident_blocks, ctx->stream, &err);
     HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
     ctx->pending_events.push_back(ev);
     if (rc) return fail(ctx, rc, err);

@@ -101,7 +101,12 @@ struct DScene {
     uint32_t sampler;
 };
 
-// kernels.hip
+// kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)
 int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, void* stream, std::string* err);
+
+// kernel_wavefront.hip: persistent wavefront state machine (default)
+int wavefront_resident_blocks(int device);
+int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
+                            int resident_blocks, void* stream, std::string* err);
 
 }  // namespace ptmi_internal

@@ -20,12 +20,16 @@ pytestmark = pytest.mark.gpu
 RMS_TOL = 1e-4  # north_star: "within 1e-4 per-channel RMS"
 
 
+KERNELS = {"wavefront": 0, "megakernel": 2}  # PTMI_FLAG_MEGAKERNEL = 2: both kernels must give the same bits
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 @pytest.mark.parametrize("case", cases.SMALL)
-def test_bit_exact_vs_oracle(case, scene_factory):
+def test_bit_exact_vs_oracle(case, kernel, scene_factory):
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
     spp = 6
-    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, spp, sampler=sampler)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, spp, sampler=sampler, flags=KERNELS[kernel])
     o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, spp, sampler=sampler)
     assert np.array_equal(count, o_count)
     assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
@@ -34,19 +38,21 @@ def test_bit_exact_vs_oracle(case, scene_factory):
     assert len(bad) == 0, f"{len(bad)} differing channel values, first at {bad[:5].tolist()}"
 
 
-def test_bit_exact_vs_oracle_1m_triangles(scene_factory):
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_bit_exact_vs_oracle_1m_triangles(kernel, scene_factory):
     name, sampler, w, h, d = cases.CASES["tris1m_160x90_d10"]
     sc = scene_factory(name, w, h)
-    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, 2)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, 2, flags=KERNELS[kernel])
     o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, 2)
     assert counters == totals
     assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
 
 
-def test_random_sampler_vs_oracle(scene_factory):
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_random_sampler_vs_oracle(kernel, scene_factory):
     sc = scene_factory("cornell", 64, 48)
-    color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 8, sampler=S.RANDOM)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 8, sampler=S.RANDOM, flags=KERNELS[kernel])
     o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 64, 48, 4, 8, sampler=S.RANDOM)
     assert np.array_equal(count, o_count) and counters == totals and np.array_equal(dep, o_dep)
     assert np.allclose(color, o_color, rtol=1e-5, atol=1e-5)
@@ -69,6 +75,18 @@ def test_iteration_ranges_compose(scene_factory):
     b, bn, _, _ = render_scene(sc, 96, 96, 8, 8, first_iteration=8)
     assert np.array_equal(an + bn, full_n)
     assert (cases.rms_per_channel(a + b, an + bn, full, full_n) <= 1e-6).all()
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_edge_sizes_and_depth_zero(kernel, scene_factory):
+    """Image sizes that are not multiples of the 8x8 tile, a 1x1 image, and ray depth 0 (no segment traced)."""
+    import copy
+    for w, h, d, spp in [(13, 7, 3, 3), (1, 1, 2, 5), (9, 17, 0, 2), (70, 5, 1, 1)]:
+        sc = copy.copy(scene_factory("cornell", 64, 48))
+        color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, spp, flags=KERNELS[kernel])
+        o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, spp)
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
+        assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and counters == totals, (w, h, d)
 
 
 def test_clear_and_reinitialize(scene_factory):
