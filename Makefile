@@ -27,3 +27,7 @@ ref:
 
 clean:
 	rm -rf $(LIBDIR) oracle/build oracle/_ref
+
+# register / LDS budget of both kernels (occupancy is VGPR-bound: read this after every kernel edit)
+resources:
+	@for f in kernels kernel_wavefront; do $(HIPCC) $(HIPFLAGS) $(EXTRA) --cuda-device-only -c $(CSRC)/$$f.hip -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|LDS Size|Spill" | sed 's/.*remark: *//' | tr '\n' ' '; echo; done

@@ -105,6 +105,7 @@ def main():
 
     kernel_ms, launches = be.kernel_time()
     c1 = be.counters()
+    sched = be.scheduler_stats()
     delta = {k: c1[k] - c0[k] for k in c1}
 
     # whole-job aggregate: sum the counters, take the max time
@@ -150,6 +151,11 @@ def main():
                          "box_tests_per_path": delta["box_tests"] / max(delta["paths"], 1),
                          "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1)},
         }
+        if sched["trips_node"]:
+            out["wave_scheduler"] = {k: round(sched["lanes_" + k] / (64.0 * sched["trips_" + k]), 3) if sched["trips_" + k] else None
+                                     for k in ("node", "triangle", "path")}
+            tot = sum(sched["trips_" + k] for k in ("node", "triangle", "path"))
+            out["wave_scheduler"]["trip_share"] = {k: round(sched["trips_" + k] / tot, 3) for k in ("node", "triangle", "path")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, D, args.cpu_rows)
         print(json.dumps(out), flush=True)
@@ -165,16 +171,17 @@ def cpu_baseline(scene, W, H, D, rows):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
     cores = host_cores()
+    n_iter = 1
     if rows <= 0:
-        # ~0.014 Mpaths/s/thread on this scene: aim at ~15 s
-        rows = max(cores, min(H, int(15 * 0.014e6 * cores / W)))
-        rows = (rows // cores) * cores or cores
-    # same camera, same pixels: the sample renders rows [0, rows) of the full-size image
+        # ~0.04 Mpaths/s/thread on this scene: aim at 10-30 s of CPU work, whole images first
+        target_paths = 15 * 0.04e6 * cores
+        n_iter = max(1, int(target_paths // (W * H)))
+        rows = H if n_iter >= 1 and target_paths >= W * H else max(cores, int(target_paths // W))
     t0 = time.perf_counter()
-    _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores)
+    _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores, n_iter)
     dt = time.perf_counter() - t0
     return {"value": totals["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"iteration 0 of rows 0..{rows - 1} of the {W}x{H} image ({rows * W} paths, "
+            "sample": f"iterations 0..{n_iter - 1} of rows 0..{rows - 1} of the {W}x{H} image ({n_iter * rows * W} paths, "
                       f"{totals['segments']} segments) in {dt:.1f} s on {cores} threads",
             "Mpaths/s": totals["paths"] / dt / 1e6}
 
@@ -191,7 +198,7 @@ def host_cores():
     return n
 
 
-def oracle_rows(O, scene, W, H, D, rows, threads):
+def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1):
     """Render iteration 0 for the first `rows` rows by running the oracle on a W x rows 'image' whose
     camera rays equal those of rows 0..rows-1 of the full image: seed and jitter depend on (x, y, W, H),
     so the full-size H is kept and only the row loop is cut short."""
@@ -210,7 +217,7 @@ def oracle_rows(O, scene, W, H, D, rows, threads):
     lib.pto_render_rows.argtypes = [C.POINTER(O.PtoScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(O.PtoBuffers), C.c_int, C.POINTER(O.PtoTotals)]
     lib.pto_render_rows.restype = None
-    lib.pto_render_rows(C.byref(osc.c), 0, 1, 0, rows, C.byref(buf), threads, C.byref(tot))
+    lib.pto_render_rows(C.byref(osc.c), 0, n_iter, 0, rows, C.byref(buf), threads, C.byref(tot))
     return color, count, (dep, bbx, tri), tot.as_dict()
 
 

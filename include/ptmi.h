@@ -91,6 +91,15 @@ typedef struct ptmi_counters {
     uint64_t triangle_tests; /* sum of numIntersectedTri incl. shadow rays */
 } ptmi_counters;
 
+/* Wave-scheduler statistics of the persistent wavefront kernel since the last clear: how many loop trips a
+ * wave spent on each step kind and how many of its 64 lanes were active in them (lanes / (64 * trips) =
+ * SIMD utilisation of that kind).  All zero for the one-path-per-lane kernel. */
+typedef struct ptmi_scheduler_stats {
+    uint64_t trips_node, lanes_node;         /* inner-node steps */
+    uint64_t trips_triangle, lanes_triangle; /* triangle tests */
+    uint64_t trips_path, lanes_path;         /* path logic (shade / shadow set-up / scatter / regenerate) */
+} ptmi_scheduler_stats;
+
 /* ---- lifecycle ---------------------------------------------------------- */
 
 /* Replaces OpenCL_SetupContext (OpenCL.cpp:316-402): picks the device, creates
@@ -133,6 +142,7 @@ void ptmi_release(ptmi_ctx* ctx);
 /* ---- measurement / plumbing -------------------------------------------- */
 
 int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out);
+int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out);
 
 /* Device time of the integrator kernel launches issued by ptmi_render since the
  * last call, measured with HIP events on the context's stream.  Synchronises. */

@@ -25,7 +25,8 @@ import numpy as np
 
 from . import structs as S
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libptmi.so")
+# PTMI_LIBRARY lets a developer A/B another in-tree build of the same ABI (tools/sweep_variants.sh)
+_LIB_PATH = os.environ.get("PTMI_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libptmi.so")
 _lib = None
 
 
@@ -66,12 +67,21 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class SchedulerStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("trips_node", "lanes_node", "trips_triangle", "lanes_triangle", "trips_path",
+                                         "lanes_path")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 FLAG_NO_HISTOGRAMS = 1
 FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_kernel_time",
+               "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_last_error",
                "ptmi_abi_version", "ptmi_device_count", "ptmi_bvh_create"]
 
@@ -99,6 +109,7 @@ def load_library():
     lib.ptmi_release.argtypes = [vp]
     lib.ptmi_release.restype = None
     lib.ptmi_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.ptmi_get_scheduler_stats.argtypes = [vp, C.POINTER(SchedulerStats)]
     lib.ptmi_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
     lib.ptmi_set_stream.argtypes = [vp, vp]
     lib.ptmi_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -217,6 +228,11 @@ class Backend:
         c = Counters()
         self._check(self._lib.ptmi_get_counters(self._ctx, C.byref(c)))
         return c.as_dict()
+
+    def scheduler_stats(self):
+        s = SchedulerStats()
+        self._check(self._lib.ptmi_get_scheduler_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
 
     def kernel_time(self):
         """(total_ms, launches) of the integrator kernel since the last call (HIP events on its stream)."""

@@ -36,7 +36,13 @@ namespace ptmi_dev {
 
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
-constexpr int kPostThreshold = 16;  // lanes waiting for path logic before the wave spends a trip on it
+#ifndef PTMI_WF_POST_THRESHOLD
+#define PTMI_WF_POST_THRESHOLD 12
+#endif
+#ifndef PTMI_WF_MIN_WAVES
+#define PTMI_WF_MIN_WAVES 5
+#endif
+constexpr int kPostThreshold = PTMI_WF_POST_THRESHOLD;  // lanes waiting for path logic before the wave spends a trip on it
 
 __device__ __forceinline__ void decode_leaf(const DScene& sc, uint32_t ref, uint32_t& tri_i, uint32_t& tri_end)
 {
@@ -51,11 +57,17 @@ __device__ __forceinline__ void decode_leaf(const DScene& sc, uint32_t ref, uint
     tri_end = start + count;
 }
 
-__global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene sc, const uint32_t first_iteration,
+__global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(const DScene sc, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t n_jobs,
                                                                     uint32_t* __restrict__ job_counter)
 {
+    // traversal stacks: [level][lane], one dword per entry, as many levels as the tree is deep (the reference
+    // reserves 30, FullKernel.cl:627; the deepest possible chain of pending far children is the tree depth)
+#ifdef PTMI_WF_STATIC_STACK
     __shared__ uint32_t stack_mem[kWfStack * kWfBlock];
+#else
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_mem[];
+#endif
     __shared__ unsigned long long block_counters[C_COUNT];
 
     const uint32_t tid = threadIdx.x;
@@ -98,6 +110,9 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
     // totals
     unsigned long long n_bbx = 0, n_tri = 0;
     uint32_t n_seg = 0, n_shadow = 0, n_hits = 0, n_paths = 0;
+    // wave-uniform scheduler statistics (scalar registers): trips and active lanes per step kind
+    uint32_t trips_i = 0, trips_t = 0, trips_p = 0;
+    unsigned long long lanes_i = 0, lanes_t = 0, lanes_p = 0;
 
     // statistics + accumulation of a finished path (FullKernel.cl:1319-1345)
     auto finish_path = [&]() {
@@ -124,6 +139,18 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
         cur = REF_NONE; tri_i = tri_end = 0;
     };
 
+    // Begin a BVH query at the root.  Invariant kept by every step: outside a leaf's triangle range `cur`
+    // is an inner-node reference or REF_NONE; a leaf reference is decoded into [tri_i, tri_end) as soon as
+    // the range is free.
+    auto start_query = [&]() {
+        cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+        found = false;
+        if (cur & REF_LEAF) {  // the whole scene is one leaf
+            decode_leaf(sc, cur, tri_i, tri_end);
+            cur = REF_NONE;
+        }
+    };
+
     for (;;) {
         const bool pending = !need_path && tri_i < tri_end;
         const bool want_inner = !need_path && !pending && cur != REF_NONE;
@@ -132,8 +159,13 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
         if ((m_t | m_i | m_p) == 0ull) break;
         const int n_t = __popcll(m_t), n_i = __popcll(m_i), n_p = __popcll(m_p);
 
+        // Progress guarantee: the chosen branch always has at least one lane (the loop has left above when
+        // all three masks are empty), so every trip advances some lane and the wave drains.
+        // (Keep the condition inline: hoisting it into bool variables makes hipcc 7.2 structure the loop
+        // differently and costs 36 VGPRs = one wave per SIMD; check `make resources` after every edit.)
         if (n_p >= kPostThreshold || (n_t == 0 && n_i == 0)) {
             // ================================ P: path logic ========================================
+            trips_p++; lanes_p += n_p;
             if (want_post) {
                 bool end_path = false;
                 bool start_shadow = false, do_scatter = false;
@@ -171,8 +203,7 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
                         ray_set_direction(r, full);
                         limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
                         shadow = true;
-                        found = false;
-                        cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+                        start_query();
                         n_shadow++;
                     }
                     if (do_scatter) {
@@ -186,8 +217,7 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
                             end_path = true;
                         } else {
                             limit = INFINITY;
-                            found = false;
-                            cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+                            start_query();
                             n_seg++;
                         }
                     }
@@ -245,39 +275,44 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
                     need_path = false;
                     if (sc.max_depth > 0) {
                         limit = INFINITY;
-                        cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+                        start_query();
                         n_seg++;
                     } else {
                         finish_path();  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
                     }
                 }
             }
-        } else if (n_t >= n_i) {
-            // ================================ T: one triangle test =================================
-            if (pending) {
-                Hit h;
-                p_tri++;
-                if (tri_hit(&sc.tris[tri_i], r, limit, h)) {
-                    found = true;
-                    if (shadow) {  // any hit ends a shadow query (FullKernel.cl:724-727)
-                        tri_end = tri_i;
-                        cur = REF_NONE; top = 0;
-                    } else {
-                        h.tri = tri_i;
-                        hit = h;
-                    }
-                }
-                tri_i++;
-            }
         } else {
-            // ================================ I: one node step =====================================
-            if (want_inner) {
-                if (cur & REF_LEAF) {
-                    decode_leaf(sc, cur, tri_i, tri_end);
-                    cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
+            // ===================== traversal trip: EVERY traversing lane takes one step ====================
+            // A DNode and a DTri are both one aligned 64-byte record, so node lanes and triangle lanes issue
+            // the same four dwordx4 loads and the wave pays the memory latency once for both kinds.
+            trips_i += n_i ? 1u : 0u; lanes_i += n_i;
+            trips_t += n_t ? 1u : 0u; lanes_t += n_t;
+            if (pending || want_inner) {
+                const float4* rec = pending ? reinterpret_cast<const float4*>(&sc.tris[tri_i])
+                                            : reinterpret_cast<const float4*>(&sc.nodes[cur & REF_INDEX_MASK_INNER]);
+                const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+                if (pending) {
+                    // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
+                    Hit h;
+                    p_tri++;
+                    if (tri_hit(v4(a), v4(b), v4(c), v4(d), r, limit, h)) {
+                        found = true;
+                        if (shadow) {  // any hit ends a shadow query (:724-727)
+                            tri_end = tri_i;
+                            cur = REF_NONE; top = 0;
+                        } else {
+                            h.tri = tri_i;
+                            hit = h;
+                        }
+                    }
+                    tri_i++;
+                    if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {  // next pending node is a leaf too
+                        decode_leaf(sc, cur, tri_i, tri_end);
+                        cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
+                    }
                 } else {
-                    const float4* np = reinterpret_cast<const float4*>(&sc.nodes[cur & REF_INDEX_MASK_INNER]);
-                    const float4 a = np[0], b = np[1], c = np[2], d = np[3];
+                    // ---- one inner-node step (:660-697)
                     const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
                     const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
                     const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
@@ -288,14 +323,9 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
                     p_bbx += 2;
                     const uint32_t near_ref = fwd ? ref1 : ref2, far_ref = fwd ? ref2 : ref1;
                     const bool near_hit = fwd ? h1 : h2, far_hit = fwd ? h2 : h1;
-                    if (near_hit) {
-                        if (far_hit) stack[(top++) * kWfBlock] = far_ref;
-                        cur = near_ref;
-                    } else if (far_hit) {
-                        cur = far_ref;
-                    } else {
-                        cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
-                    }
+                    if (near_hit & far_hit) stack[(top++) * kWfBlock] = far_ref;
+                    cur = near_hit ? near_ref : far_ref;
+                    if (!(near_hit | far_hit)) cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
                     if (cur != REF_NONE && (cur & REF_LEAF)) {  // reached a leaf: its triangles are next
                         decode_leaf(sc, cur, tri_i, tri_end);
                         cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
@@ -311,6 +341,14 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
     atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
     atomicAdd(&block_counters[C_BBX], n_bbx);
     atomicAdd(&block_counters[C_TRI], n_tri);
+    if ((tid & 63u) == 0) {  // one lane per wave: the scheduler counters are wave-uniform
+        atomicAdd(&block_counters[C_TRIPS_I], (unsigned long long)trips_i);
+        atomicAdd(&block_counters[C_LANES_I], lanes_i);
+        atomicAdd(&block_counters[C_TRIPS_T], (unsigned long long)trips_t);
+        atomicAdd(&block_counters[C_LANES_T], lanes_t);
+        atomicAdd(&block_counters[C_TRIPS_P], (unsigned long long)trips_p);
+        atomicAdd(&block_counters[C_LANES_P], lanes_p);
+    }
     __syncthreads();
     if (tid < C_COUNT) atomicAdd(&sc.counters[tid], block_counters[tid]);
 }
@@ -319,19 +357,31 @@ __global__ void __launch_bounds__(kWfBlock) render_wavefront_kernel(const DScene
 
 namespace ptmi_internal {
 
-int wavefront_resident_blocks(int device)
+static size_t wavefront_lds_bytes(uint32_t stack_levels)
+{
+#ifdef PTMI_WF_STATIC_STACK
+    (void)stack_levels;
+    return 0;
+#endif
+    if (stack_levels < 1) stack_levels = 1;
+    if (stack_levels > (uint32_t)ptmi_dev::kWfStack) stack_levels = ptmi_dev::kWfStack;
+    return (size_t)stack_levels * ptmi_dev::kWfBlock * sizeof(uint32_t);
+}
+
+int wavefront_resident_blocks(int device, uint32_t stack_levels)
 {
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel, ptmi_dev::kWfBlock, 0) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel, ptmi_dev::kWfBlock,
+                                                     wavefront_lds_bytes(stack_levels)) != hipSuccess)
         return 0;
     if (per_cu < 1) per_cu = 1;
     return per_cu * prop.multiProcessorCount;
 }
 
 int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
-                            int resident_blocks, void* stream, std::string* err)
+                            int resident_blocks, uint32_t stack_levels, void* stream, std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
     const uint32_t tiles = ((sc.width + 7u) / 8u) * ((sc.height + 7u) / 8u);
@@ -340,8 +390,9 @@ int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
         if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
-        hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel, dim3(blocks), dim3(ptmi_dev::kWfBlock), 0,
-                           (hipStream_t)stream, sc, first_iteration, n_iterations, n_jobs, job_counter);
+        hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel, dim3(blocks), dim3(ptmi_dev::kWfBlock),
+                           wavefront_lds_bytes(stack_levels), (hipStream_t)stream, sc, first_iteration, n_iterations,
+                           n_jobs, job_counter);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {

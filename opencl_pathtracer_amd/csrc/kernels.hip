@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const u
         atomicAdd(&block_counters[C_TRI], n_tri);
     }
     __syncthreads();
-    if (tid < C_COUNT) atomicAdd(&sc.counters[tid], block_counters[tid]);
+    if (tid <= C_TRI) atomicAdd(&sc.counters[tid], block_counters[tid]);
 }
 
 }  // namespace ptmi_dev

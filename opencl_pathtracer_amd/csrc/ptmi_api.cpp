@@ -46,6 +46,7 @@ struct ptmi_ctx {
     unsigned long long* d_counters = nullptr;
     uint32_t* d_job_counter = nullptr;
     int resident_blocks = 0;
+    uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     DScene ds{};
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -291,7 +292,6 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
         return fail(nullptr, PTMI_ERR_HIP, msg);
     }
     ctx->stream = ctx->own_stream;
-    ctx->resident_blocks = wavefront_resident_blocks(ctx->device);
     *out = ctx;
     return PTMI_OK;
 }
@@ -357,6 +357,9 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
     std::memcpy(ds.cam_right, &sc->camera_right, 16);
     std::memcpy(ds.cam_up, &sc->camera_up, 16);
+    // a ray holds at most one pending far child per level it has descended
+    ctx->stack_levels = lay.max_depth < 1 ? 1 : lay.max_depth;
+    ctx->resident_blocks = wavefront_resident_blocks(ctx->device, ctx->stack_levels);
     ds.root_ref = lay.root_ref;
     ds.width = ctx->cfg.image_width;
     ds.height = ctx->cfg.image_height;
@@ -407,7 +410,7 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
     const int rc = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL)
                        ? launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err)
                        : launch_render_wavefront(ctx->ds, first_iteration, n_iterations, ctx->d_job_counter,
-                                                 ctx->resident_blocks, ctx->stream, &err);
+                                                 ctx->resident_blocks, ctx->stack_levels, ctx->stream, &err);
     HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
     ctx->pending_events.push_back(ev);
     if (rc) return fail(ctx, rc, err);
@@ -457,6 +460,20 @@ int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     out->paths = h[C_PATHS]; out->segments = h[C_SEGMENTS]; out->surface_hits = h[C_HITS];
     out->shadow_rays = h[C_SHADOW]; out->box_tests = h[C_BBX]; out->triangle_tests = h[C_TRI];
+    return PTMI_OK;
+}
+
+int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
+{
+    if (!ctx || !out) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_get_scheduler_stats before ptmi_initialize_memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[C_COUNT];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    out->trips_node = h[C_TRIPS_I]; out->lanes_node = h[C_LANES_I];
+    out->trips_triangle = h[C_TRIPS_T]; out->lanes_triangle = h[C_LANES_T];
+    out->trips_path = h[C_TRIPS_P]; out->lanes_path = h[C_LANES_P];
     return PTMI_OK;
 }
 

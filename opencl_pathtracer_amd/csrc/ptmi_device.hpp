@@ -100,23 +100,25 @@ __device__ __forceinline__ V4 put_in_same_hemisphere(V4 v, V4 n)
 // which the caller bumps.
 __device__ __forceinline__ bool box_hit(const float lo[3], const float hi[3], bool is_empty, const Ray& r, float limit)
 {
+    // bitwise & | on the comparison results: they become scalar ops on lane masks; && || would be compiled
+    // into a chain of ~30 tiny divergent blocks (measured: 5 % slower)
     const bool px = r.d.x > 0, py = r.d.y > 0, pz = r.d.z > 0;
     float tmin = ((px ? lo[0] : hi[0]) - r.o.x) * r.ix;
     float tmax = ((px ? hi[0] : lo[0]) - r.o.x) * r.ix;
-    bool ok = !(tmin < 0 && tmax < 0);
+    bool miss = (tmin < 0) & (tmax < 0);
     const float tymin = ((py ? lo[1] : hi[1]) - r.o.y) * r.iy;
     const float tymax = ((py ? hi[1] : lo[1]) - r.o.y) * r.iy;
-    ok = ok && !(tymin < 0 && tymax < 0);
-    ok = ok && !(tmin > tymax || tymin > tmax);
+    miss |= (tymin < 0) & (tymax < 0);
+    miss |= (tmin > tymax) | (tymin > tmax);
     tmin = tymin > tmin ? tymin : tmin;
     tmax = tymax < tmax ? tymax : tmax;
     const float tzmin = ((pz ? lo[2] : hi[2]) - r.o.z) * r.iz;
     const float tzmax = ((pz ? hi[2] : lo[2]) - r.o.z) * r.iz;
-    ok = ok && !(tzmin < 0 && tzmax < 0);
-    ok = ok && !(tmin > tzmax || tzmin > tmax);
+    miss |= (tzmin < 0) & (tzmax < 0);
+    miss |= (tmin > tzmax) | (tzmin > tmax);
     tmin = tzmin > tmin ? tzmin : tmin;
-    ok = ok && (tmin < 0 || !(tmin > limit));
-    return ok && !is_empty;
+    miss |= !(tmin < 0) & (tmin > limit);
+    return !(miss | is_empty);
 }
 
 struct Hit {
@@ -128,10 +130,11 @@ struct Hit {
 
 // Triangle_Intersects, FullKernel.cl:519-589, without the colour fetch (done
 // once for the final hit: the fetch is a pure function of triangle, side, s, t).
-__device__ __forceinline__ bool tri_hit(const DTri* __restrict__ tp, const Ray& r, float& limit, Hit& h)
+// Early exits kept on purpose: measured on MI355X, the straight-line form (all rejections OR-ed at the end)
+// was 29 % slower on the 1M-triangle workload -- whole groups of lanes do leave at the distance test.
+__device__ __forceinline__ bool tri_hit(const V4 S1, const V4 S2, const V4 S3, const V4 N, const Ray& r, float& limit,
+                                        Hit& h)
 {
-    const float4* q4 = reinterpret_cast<const float4*>(tp);
-    const V4 S1 = v4(q4[0]), S2 = v4(q4[1]), S3 = v4(q4[2]), N = v4(q4[3]);
     const V4 u = S2 - S1;
     const V4 v = S3 - S1;
     const float d = dot(N, S1);
@@ -155,6 +158,12 @@ __device__ __forceinline__ bool tri_hit(const DTri* __restrict__ tp, const Ray& 
     h.t = t;
     h.front = nd < 0;
     return true;
+}
+
+__device__ __forceinline__ bool tri_hit(const DTri* __restrict__ tp, const Ray& r, float& limit, Hit& h)
+{
+    const float4* q4 = reinterpret_cast<const float4*>(tp);
+    return tri_hit(v4(q4[0]), v4(q4[1]), v4(q4[2]), v4(q4[3]), r, limit, h);
 }
 
 // Texture_GetPixelColorValue, header.cl:430-459

@@ -74,7 +74,12 @@ struct DBigLeaf {
     uint32_t start, count;
 };
 
-enum CounterSlot { C_PATHS = 0, C_SEGMENTS, C_HITS, C_SHADOW, C_BBX, C_TRI, C_COUNT };
+enum CounterSlot {
+    C_PATHS = 0, C_SEGMENTS, C_HITS, C_SHADOW, C_BBX, C_TRI,
+    // wave scheduler of the wavefront kernel: loop trips and active lanes per step kind
+    C_TRIPS_I, C_LANES_I, C_TRIPS_T, C_LANES_T, C_TRIPS_P, C_LANES_P,
+    C_COUNT
+};
 
 // Everything a launch needs, passed by value (lives in SGPRs / kernarg).
 struct DScene {
@@ -105,8 +110,9 @@ struct DScene {
 int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, void* stream, std::string* err);
 
 // kernel_wavefront.hip: persistent wavefront state machine (default)
-int wavefront_resident_blocks(int device);
+// stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30)
+int wavefront_resident_blocks(int device, uint32_t stack_levels);
 int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
-                            int resident_blocks, void* stream, std::string* err);
+                            int resident_blocks, uint32_t stack_levels, void* stream, std::string* err);
 
 }  // namespace ptmi_internal
