@@ -11,8 +11,16 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno
 LIB_SRCS   := $(CSRC)/kernels.hip $(CSRC)/kernel_wavefront.hip $(CSRC)/ptmi_api.cpp $(CSRC)/bvh_build.cpp
 LIB_HDRS   := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp)
 
-.PHONY: all lib oracle ref clean
-all: lib oracle
+.PHONY: all lib shim oracle ref clean resources
+all: lib shim oracle
+
+# C++ host shim with the reference's own backend signatures (namespace PathTracerNS) + the test driver that
+# plays PathTracer_Main's part.  Plain g++: the shim is host code above the C ABI.
+shim: $(LIBDIR)/libpathtracer_hip.so $(LIBDIR)/shim_driver
+$(LIBDIR)/libpathtracer_hip.so: $(CSRC)/PathTracer_HIP.cpp include/pathtracer_backend.hpp include/ptmi.h $(LIBDIR)/libptmi.so
+	g++ -std=c++14 -O2 -fPIC -shared -Iinclude $(CSRC)/PathTracer_HIP.cpp -o $@ -L$(LIBDIR) -lptmi -Wl,-rpath,'$$ORIGIN'
+$(LIBDIR)/shim_driver: tests/shim_driver.cpp $(LIBDIR)/libpathtracer_hip.so
+	g++ -std=c++14 -O2 -Iinclude tests/shim_driver.cpp -o $@ -L$(LIBDIR) -lpathtracer_hip -lptmi -Wl,-rpath,'$$ORIGIN'
 
 lib: $(LIBDIR)/libptmi.so
 $(LIBDIR)/libptmi.so: $(LIB_SRCS) $(LIB_HDRS)

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--kernel", choices=["wavefront", "megakernel"], default="wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo is a rehearsal of the N>1 control flow on a one-GPU box "
+                         "(all ranks share GPU 0, accumulators are reduced through host memory)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of iteration 0 the CPU baseline renders (0 = auto)")
     args = ap.parse_args()
 
@@ -59,15 +62,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the integrator has no CPU path")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks may share a card
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     W, H, D, B = args.width, args.height, args.depth, args.spp_per_step
     t0 = time.time()
@@ -79,13 +86,18 @@ def main():
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)
     fb.bind(be)
-    stream = torch.cuda.current_stream(device)
+    # One explicit stream for the kernels AND the collective: the reduce must be ordered after the last
+    # launch.  (torch's default stream has handle 0, which ptmi_set_stream reads as "own stream".)
+    stream = torch.cuda.Stream(device)
+    assert stream.cuda_stream != 0
     be.set_stream(stream.cuda_stream)
 
     def step(s):
         # global step s covers iteration ids [s*B*world, (s+1)*B*world); this rank takes its block of B
         be.render((s * world + rank) * B, B)
 
+    torch.cuda.synchronize(device)
+    torch.cuda.set_stream(stream)
     for s in range(args.warmup):
         step(s)
     torch.cuda.synchronize(device)
@@ -97,7 +109,12 @@ def main():
     t_start = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
         step(s)
-    fb.reduce_to(0)  # the one collective of a sharded render (no-op at N=1)
+    if args.backend == "gloo" and world > 1:  # rehearsal path: gloo has no device tensors
+        host = fb.buffer.cpu()
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+        fb.buffer.copy_(host)
+    else:
+        fb.reduce_to(0)  # the one collective of a sharded render: RCCL reduce over xGMI (no-op at N=1)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -109,8 +126,9 @@ def main():
     delta = {k: c1[k] - c0[k] for k in c1}
 
     # whole-job aggregate: sum the counters, take the max time
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    cnt = torch.tensor([delta[k] for k in sorted(delta)], dtype=torch.int64, device=device)
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    cnt = torch.tensor([delta[k] for k in sorted(delta)], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
@@ -126,6 +144,7 @@ def main():
         b_alg = algorithmic_bytes(delta, n_pix, launches)
         avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = b_alg / max(launches, 1) / avg_launch_s / 1e9
+        traffic = committed_traffic(args, W, H, D, B)
         out = {
             "metric": "Msamples/s (paths x bounces) at 1920x1080",
             "value": total["segments"] / elapsed / 1e6,
@@ -144,7 +163,7 @@ def main():
             "Mshadow_rays/s": total["shadow_rays"] / elapsed / 1e6,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "render_wavefront_kernel" if args.kernel == "wavefront" else "render_kernel",
                          "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
@@ -163,6 +182,18 @@ def main():
     be.release()
     if world > 1:
         dist.destroy_process_group()
+
+
+def committed_traffic(args, W, H, D, B):
+    """roofline.traffic: memory-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled as the gfx950 note of
+    MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads).  Only quoted for the configuration it was
+    measured on; None otherwise (bench.py itself cannot read PMC counters)."""
+    path = os.path.join(ROOT, "profiles", "r01_wavefront_pmc.json")
+    if not os.path.exists(path) or (args.scene, W, H, D, B, args.kernel) != ("tris1m", 1920, 1080, 10, 2, "wavefront"):
+        return None
+    pmc = json.load(open(path))
+    return (2.0 * pmc["FETCH_SIZE"]["per_launch_mean"] + pmc["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
 
 
 def cpu_baseline(scene, W, H, D, rows):

@@ -1,0 +1,87 @@
+// pathtracer_backend.hpp - the reference's backend interface, for hosts that do not have its headers at hand.
+//
+// The reference's orchestration (Controleur/PathTracer.cpp:74,76,82) drives its device backend through three
+// free functions of namespace PathTracerNS declared in Controleur/PathTracer_OpenCL.h:17-19, all taking the
+// global scene record `GlobalVars` (Controleur/PathTracer_Structs.h:145-189).  opencl_pathtracer_amd/csrc/
+// PathTracer_HIP.cpp implements exactly those three signatures on top of the C ABI (ptmi.h).
+//
+// A maintainer of the reference compiles PathTracer_HIP.cpp against THEIR headers (define
+// PTMI_USE_REFERENCE_HEADERS).  This header is the stand-alone alternative: the same
+// names with the same binary layout (x86-64 / MSVC x64: the scene structs of ptmi_scene.h under the
+// reference's names, and GlobalVars field for field), so the shim and its tests build anywhere.
+// tests/test_shim.py checks the layout against the reference header where the reference tree exists.
+#pragma once
+
+#include <cstdint>
+
+#include "ptmi_scene.h"
+
+namespace PathTracerNS {
+
+typedef unsigned int uint;
+typedef ptmi_float4 Float4;
+typedef ptmi_float4 RGBAColor;
+typedef ptmi_uchar4 Uchar4;
+typedef ptmi_node Node;
+typedef ptmi_triangle Triangle;
+typedef ptmi_light Light;
+typedef ptmi_material Material;
+typedef ptmi_texture Texture;
+typedef ptmi_sky Sky;
+
+enum Sampler { JITTERED, RANDOM, UNIFORM };  // PathTracer_Structs.h:130-135
+
+class PathTracerDialog;
+class PathTracerImporter;
+
+// PathTracer_Structs.h:145-189, same order, same types
+struct GlobalVars {
+    PathTracerDialog* window;
+    PathTracerImporter* importer;
+
+    Float4 cameraDirection;
+    Float4 cameraRight;
+    Float4 cameraUp;
+    Float4 cameraPosition;
+
+    Node* bvh;
+    Triangle* triangulation;
+    Light* lights;
+    Material* materiaux;
+    Texture* textures;
+    Uchar4* texturesData;
+
+    uint bvhSize;
+    uint triangulationSize;
+    uint lightsSize;
+    uint materiauxSize;
+    uint texturesSize;
+    uint texturesDataSize;
+    uint bvhMaxDepth;
+    Sampler sampler;
+    bool printLogInfos;
+    bool superSampling;
+
+    Sky sky;
+
+    uint imageWidth;
+    uint imageHeight;
+    uint imageSize;
+    uint rayMaxDepth;
+    RGBAColor* imageColor;
+    float* imageRayNb;
+    uint* rayDepths;
+    uint* rayIntersectedBBx;
+    uint* rayIntersectedTri;
+};
+
+// Controleur/PathTracer_OpenCL.h:17-19
+void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), uint numImagesToRender,
+                      double* pathTracingTime, double* memoryTime, double* displayTime);
+void OpenCL_InitializeMemory(GlobalVars& globalVars);
+void OpenCL_SetupContext(GlobalVars& globalVars, Sampler sampler);
+
+// Controleur/PathTracer_BVH.h: host-side producer of globalVars.bvh
+void BVH_Create(GlobalVars& globalVars);
+
+}  // namespace PathTracerNS
