@@ -37,14 +37,15 @@ def algorithmic_bytes(c, n_pixels, n_flush):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=8)
     ap.add_argument("--scene", default="tris1m")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--kernel", choices=["wavefront", "megakernel"], default="wavefront")
+    ap.add_argument("--scheduler-stats", action="store_true", help="also report wave-scheduler statistics (costs ~1 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo is a rehearsal of the N>1 control flow on a one-GPU box "
@@ -56,7 +57,7 @@ def main():
     import torch
     import torch.distributed as dist
     import opencl_pathtracer_amd as pt
-    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS, FLAG_MEGAKERNEL
+    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS, FLAG_MEGAKERNEL, FLAG_SCHEDULER_STATS
     from opencl_pathtracer_amd.distributed import FusedAccumulators
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,7 +83,8 @@ def main():
     t_scene = time.time() - t0
 
     be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=local_rank,
-                                    flags=FLAG_NO_HISTOGRAMS | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0))
+                                    flags=FLAG_NO_HISTOGRAMS | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0)
+                                    | (FLAG_SCHEDULER_STATS if args.scheduler_stats else 0))
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)
     fb.bind(be)
@@ -190,7 +192,7 @@ def committed_traffic(args, W, H, D, B):
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads).  Only quoted for the configuration it was
     measured on; None otherwise (bench.py itself cannot read PMC counters)."""
     path = os.path.join(ROOT, "profiles", "r01_wavefront_pmc.json")
-    if not os.path.exists(path) or (args.scene, W, H, D, B, args.kernel) != ("tris1m", 1920, 1080, 10, 2, "wavefront"):
+    if not os.path.exists(path) or (args.scene, W, H, D, B, args.kernel) != ("tris1m", 1920, 1080, 10, 8, "wavefront"):
         return None
     pmc = json.load(open(path))
     return (2.0 * pmc["FETCH_SIZE"]["per_launch_mean"] + pmc["WRITE_SIZE"]["per_launch_mean"]) * 1024.0

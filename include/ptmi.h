@@ -59,6 +59,7 @@ typedef struct ptmi_config {
 } ptmi_config;
 
 #define PTMI_FLAG_NO_HISTOGRAMS 1u /* skip the three per-path histogram atomics (FullKernel.cl:1319-1331); totals are still kept */
+#define PTMI_FLAG_SCHEDULER_STATS 4u /* collect ptmi_scheduler_stats (a few scalar ops per loop trip; off by default) */
 #define PTMI_FLAG_MEGAKERNEL 2u    /* one path per lane (kernels.hip) instead of the persistent wavefront kernel; same results */
 
 /* What OpenCL_InitializeMemory copies with CL_MEM_COPY_HOST_PTR and passes as
@@ -93,7 +94,8 @@ typedef struct ptmi_counters {
 
 /* Wave-scheduler statistics of the persistent wavefront kernel since the last clear: how many loop trips a
  * wave spent on each step kind and how many of its 64 lanes were active in them (lanes / (64 * trips) =
- * SIMD utilisation of that kind).  All zero for the one-path-per-lane kernel. */
+ * SIMD utilisation of that kind).  Collected only with PTMI_FLAG_SCHEDULER_STATS; all zero otherwise and for the
+ * one-path-per-lane kernel. */
 typedef struct ptmi_scheduler_stats {
     uint64_t trips_node, lanes_node;         /* inner-node steps */
     uint64_t trips_triangle, lanes_triangle; /* triangle tests */

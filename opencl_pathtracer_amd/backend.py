@@ -76,6 +76,7 @@ class SchedulerStats(C.Structure):
 
 
 FLAG_NO_HISTOGRAMS = 1
+FLAG_SCHEDULER_STATS = 4  # collect scheduler_stats() (off by default)
 FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)

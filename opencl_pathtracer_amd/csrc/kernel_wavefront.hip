@@ -6,10 +6,12 @@
 // partial exec masks.  Here instead:
 //
 //  * The grid is PERSISTENT: as many workgroups as the chip holds, alive for the whole launch.  Work is
-//    a queue of jobs, job = one pixel x all iterations of the launch, handed out 8x8-tile-wise by one
-//    atomic per wave whenever some of its lanes run dry (`dequeue` in MI355X_MICROARCH.md: the cheapest
-//    cross-CU primitive).  A lane owns its pixel: the radiance sum stays in registers and the framebuffer
-//    is read and written once per job, with no atomics, in iteration order (bit-exact accumulation).
+//    a queue of jobs, job = ONE PATH (pixel, iteration), handed out 8x8-tile-wise by one atomic per wave
+//    whenever some of its lanes run dry (`dequeue` in MI355X_MICROARCH.md: the cheapest cross-CU
+//    primitive).  A finished path stores its radiance (16 B) into a staging array [iteration][pixel]; a
+//    trivial follow-up kernel adds the staged values to the framebuffer pixel by pixel IN ITERATION ORDER,
+//    so the float sums are the reference's, bit for bit, without atomics.  (Jobs of one pixel x all
+//    iterations kept the sum in registers but left a tail of one whole job per lane: -12 % at 1080p.)
 //  * Every lane is a small STATE MACHINE over the same three step kinds:
 //        I  one inner-node step  (load one 64-byte DNode, two slab tests, push/pop on the LDS stack)
 //        T  one triangle test    (load one 64-byte DTri)
@@ -37,10 +39,10 @@ namespace ptmi_dev {
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #ifndef PTMI_WF_POST_THRESHOLD
-#define PTMI_WF_POST_THRESHOLD 12
+#define PTMI_WF_POST_THRESHOLD 8
 #endif
 #ifndef PTMI_WF_MIN_WAVES
-#define PTMI_WF_MIN_WAVES 5
+#define PTMI_WF_MIN_WAVES 4
 #endif
 constexpr int kPostThreshold = PTMI_WF_POST_THRESHOLD;  // lanes waiting for path logic before the wave spends a trip on it
 
@@ -57,9 +59,12 @@ __device__ __forceinline__ void decode_leaf(const DScene& sc, uint32_t ref, uint
     tri_end = start + count;
 }
 
+template <bool STATS>
 __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(const DScene sc, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t n_jobs,
-                                                                    uint32_t* __restrict__ job_counter)
+                                                                    uint32_t* __restrict__ job_counter,
+                                                                    const uint32_t stack_levels,
+                                                                    float* __restrict__ stage)
 {
     // traversal stacks: [level][lane], one dword per entry, as many levels as the tree is deep (the reference
     // reserves 30, FullKernel.cl:627; the deepest possible chain of pending far children is the tree depth)
@@ -74,17 +79,23 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     if (tid < C_COUNT) block_counters[tid] = 0;
     __syncthreads();
     uint32_t* const stack = &stack_mem[tid];
+    // The closest-hit record (point, s, t, triangle, side) changes only when a closer hit is accepted and is read
+    // only by path logic: it lives in LDS behind the stack, [field][lane], not in registers of the hot loop.
+#ifdef PTMI_WF_STATIC_STACK
+    __shared__ uint32_t hit_store[8 * kWfBlock];
+    uint32_t* const hit_mem = &hit_store[tid];
+#else
+    uint32_t* const hit_mem = &stack_mem[stack_levels * kWfBlock + tid];
+#endif
     const uint32_t tiles_x = (sc.width + 7u) >> 3;
     const bool owns_pixel = sc.sampler != PTMI_SAMPLER_RANDOM;
     const uint32_t it_end = first_iteration + n_iterations;
+    const uint32_t jobs_per_iteration = n_jobs / n_iterations;
 
     // ---- lane state -----------------------------------------------------------------------------
     bool alive = true;       // may still receive work
     bool need_path = true;   // no path in flight
-    bool has_pixel = false;
     uint32_t gx = 0, gy = 0, it = it_end;
-    V4 sum = v4(0, 0, 0, 0);
-    float count = 0;
     // path
     int seed = 1;
     float sample_x = 0, sample_y = 0;
@@ -98,8 +109,16 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     bool shadow = false, found = false;
     uint32_t cur = REF_NONE, tri_i = 0, tri_end = 0;
     int top = 0;
-    Hit hit;
-    hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
+    auto store_hit = [&](const Hit& h) {
+        hit_mem[0 * kWfBlock] = __float_as_uint(h.point.x); hit_mem[1 * kWfBlock] = __float_as_uint(h.point.y);
+        hit_mem[2 * kWfBlock] = __float_as_uint(h.point.z); hit_mem[3 * kWfBlock] = __float_as_uint(h.point.w);
+        hit_mem[4 * kWfBlock] = __float_as_uint(h.s); hit_mem[5 * kWfBlock] = __float_as_uint(h.t);
+        hit_mem[6 * kWfBlock] = h.tri; hit_mem[7 * kWfBlock] = h.front ? 1u : 0u;
+    };
+    auto load_hit_point = [&]() {
+        return v4(__uint_as_float(hit_mem[0 * kWfBlock]), __uint_as_float(hit_mem[1 * kWfBlock]),
+                  __uint_as_float(hit_mem[2 * kWfBlock]), __uint_as_float(hit_mem[3 * kWfBlock]));
+    };
     // saved across the shadow rays of one surface hit
     Surface sf;
     sf.Ng = sf.Ns = sf.color = v4(0, 0, 0, 0);
@@ -123,8 +142,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             if (p_tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[p_tri], 1u);
         }
         if (owns_pixel) {
-            sum = sum + radiance;
-            count = count + 1.f;
+            // JITTERED / UNIFORM: the sample lands on the work-item's own pixel (:1333-1336); stage it
+            const size_t slot = (size_t)(it - first_iteration) * ((size_t)sc.width * sc.height) + (size_t)gy * sc.width + gx;
+            reinterpret_cast<float4*>(stage)[slot] = make_float4(radiance.x, radiance.y, radiance.z, radiance.w);
         } else {
             // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345)
             const uint32_t off = sample_pixel(sc, sample_x, sample_y);
@@ -134,7 +154,6 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             atomicAdd(&sc.image_color[4 * off + 3], radiance.w);
             atomicAdd(&sc.image_ray_nb[off], 1.f);
         }
-        it++;
         need_path = true;
         cur = REF_NONE; tri_i = tri_end = 0;
     };
@@ -165,14 +184,19 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         // differently and costs 36 VGPRs = one wave per SIMD; check `make resources` after every edit.)
         if (n_p >= kPostThreshold || (n_t == 0 && n_i == 0)) {
             // ================================ P: path logic ========================================
-            trips_p++; lanes_p += n_p;
+            if (STATS) { trips_p++; lanes_p += n_p; }
             if (want_post) {
                 bool end_path = false;
                 bool start_shadow = false, do_scatter = false;
+                Hit hit;
+                hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
                 if (!need_path) {
+                    hit.point = load_hit_point();
                     if (!shadow) {
                         // closest-hit query finished (FullKernel.cl:1252-1288)
                         if (found) {
+                            hit.s = __uint_as_float(hit_mem[4 * kWfBlock]); hit.t = __uint_as_float(hit_mem[5 * kWfBlock]);
+                            hit.tri = hit_mem[6 * kWfBlock]; hit.front = hit_mem[7 * kWfBlock] != 0;
                             load_surface(sc, r, hit, sf);
                             cam_d = r.d;
                             direct = v4(0, 0, 0, 0);
@@ -225,15 +249,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 }
 
                 // ---- job hand-out: one atomic per wave for all lanes that ran dry -----------------
-                const bool want_job = need_path && it >= it_end;
-                if (want_job && has_pixel) {
-                    if (owns_pixel) {
-                        const uint32_t off = gy * sc.width + gx;
-                        *reinterpret_cast<float4*>(&sc.image_color[4 * off]) = make_float4(sum.x, sum.y, sum.z, sum.w);
-                        sc.image_ray_nb[off] = count;
-                    }
-                    has_pixel = false;
-                }
+                bool got_job = false;
+                const bool want_job = need_path;
                 const unsigned long long m_job = __ballot(want_job);
                 if (want_job) {
                     const int leader = __ffsll((long long)m_job) - 1;
@@ -245,23 +262,19 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     if (job >= n_jobs) {
                         alive = false;
                     } else {
-                        const uint32_t tile = job >> 6, in_tile = job & 63u;
+                        // iteration-major; inside an iteration 8x8 tiles in row-major order
+                        const uint32_t it_local = job / jobs_per_iteration;
+                        const uint32_t rem = job - it_local * jobs_per_iteration;
+                        const uint32_t tile = rem >> 6, in_tile = rem & 63u;
                         gx = (tile % tiles_x) * 8u + (in_tile & 7u);
                         gy = (tile / tiles_x) * 8u + (in_tile >> 3);
-                        if (gx < sc.width && gy < sc.height) {
-                            has_pixel = true;
-                            it = first_iteration;
-                            if (owns_pixel) {
-                                const uint32_t off = gy * sc.width + gx;
-                                sum = v4(*reinterpret_cast<const float4*>(&sc.image_color[4 * off]));
-                                count = sc.image_ray_nb[off];
-                            }
-                        }  // else: edge tile, pixel outside the image: ask again next time
+                        it = first_iteration + it_local;
+                        got_job = gx < sc.width && gy < sc.height;  // edge tiles: pixel outside the image, ask again
                     }
                 }
 
                 // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
-                if (need_path && has_pixel && it < it_end) {
+                if (got_job) {
                     seed = lcg_seed(gx, gy, sc.width, sc.height, it);
                     draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
                     r.o = v4(sc.cam_pos);
@@ -286,8 +299,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             // ===================== traversal trip: EVERY traversing lane takes one step ====================
             // A DNode and a DTri are both one aligned 64-byte record, so node lanes and triangle lanes issue
             // the same four dwordx4 loads and the wave pays the memory latency once for both kinds.
-            trips_i += n_i ? 1u : 0u; lanes_i += n_i;
-            trips_t += n_t ? 1u : 0u; lanes_t += n_t;
+            if (STATS) {
+                trips_i += n_i ? 1u : 0u; lanes_i += n_i;
+                trips_t += n_t ? 1u : 0u; lanes_t += n_t;
+            }
             if (pending || want_inner) {
                 const float4* rec = pending ? reinterpret_cast<const float4*>(&sc.tris[tri_i])
                                             : reinterpret_cast<const float4*>(&sc.nodes[cur & REF_INDEX_MASK_INNER]);
@@ -303,7 +318,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                             cur = REF_NONE; top = 0;
                         } else {
                             h.tri = tri_i;
-                            hit = h;
+                            store_hit(h);
                         }
                     }
                     tri_i++;
@@ -341,7 +356,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
     atomicAdd(&block_counters[C_BBX], n_bbx);
     atomicAdd(&block_counters[C_TRI], n_tri);
-    if ((tid & 63u) == 0) {  // one lane per wave: the scheduler counters are wave-uniform
+    if (STATS && (tid & 63u) == 0) {  // one lane per wave: the scheduler counters are wave-uniform
         atomicAdd(&block_counters[C_TRIPS_I], (unsigned long long)trips_i);
         atomicAdd(&block_counters[C_LANES_I], lanes_i);
         atomicAdd(&block_counters[C_TRIPS_T], (unsigned long long)trips_t);
@@ -353,9 +368,36 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     if (tid < C_COUNT) atomicAdd(&sc.counters[tid], block_counters[tid]);
 }
 
+// Adds the staged radiances of one launch to the accumulators, per pixel in iteration order:
+// sumAfter = sumBefore + radiance; nRayAfter = nRayBefore + 1 (FullKernel.cl:1339-1345), n_iterations times.
+__global__ void __launch_bounds__(256) accumulate_staged_kernel(float* __restrict__ image_color,
+                                                                 float* __restrict__ image_ray_nb,
+                                                                 const float* __restrict__ stage, const uint32_t n_pixels,
+                                                                 const uint32_t n_iterations)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    float4 sum = reinterpret_cast<const float4*>(image_color)[p];
+    float count = image_ray_nb[p];
+    for (uint32_t k = 0; k < n_iterations; k++) {
+        const float4 r = reinterpret_cast<const float4*>(stage)[(size_t)k * n_pixels + p];
+        sum.x = sum.x + r.x; sum.y = sum.y + r.y; sum.z = sum.z + r.z; sum.w = sum.w + r.w;
+        count = count + 1.f;
+    }
+    reinterpret_cast<float4*>(image_color)[p] = sum;
+    image_ray_nb[p] = count;
+}
+
 }  // namespace ptmi_dev
 
 namespace ptmi_internal {
+
+static uint32_t clamp_levels(uint32_t stack_levels)
+{
+    if (stack_levels < 1) stack_levels = 1;
+    if (stack_levels > (uint32_t)ptmi_dev::kWfStack) stack_levels = ptmi_dev::kWfStack;
+    return stack_levels;
+}
 
 static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
@@ -363,9 +405,8 @@ static size_t wavefront_lds_bytes(uint32_t stack_levels)
     (void)stack_levels;
     return 0;
 #endif
-    if (stack_levels < 1) stack_levels = 1;
-    if (stack_levels > (uint32_t)ptmi_dev::kWfStack) stack_levels = ptmi_dev::kWfStack;
-    return (size_t)stack_levels * ptmi_dev::kWfBlock * sizeof(uint32_t);
+    stack_levels = clamp_levels(stack_levels);
+    return (size_t)(stack_levels + 8) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // stack + closest-hit record
 }
 
 int wavefront_resident_blocks(int device, uint32_t stack_levels)
@@ -373,7 +414,7 @@ int wavefront_resident_blocks(int device, uint32_t stack_levels)
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel, ptmi_dev::kWfBlock,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel<false>, ptmi_dev::kWfBlock,
                                                      wavefront_lds_bytes(stack_levels)) != hipSuccess)
         return 0;
     if (per_cu < 1) per_cu = 1;
@@ -381,19 +422,36 @@ int wavefront_resident_blocks(int device, uint32_t stack_levels)
 }
 
 int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
-                            int resident_blocks, uint32_t stack_levels, void* stream, std::string* err)
+                            int resident_blocks, uint32_t stack_levels, bool scheduler_stats, float* stage,
+                            void* stream, std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
     const uint32_t tiles = ((sc.width + 7u) / 8u) * ((sc.height + 7u) / 8u);
-    const uint32_t n_jobs = tiles * 64u;
+    const uint64_t jobs64 = (uint64_t)tiles * 64u * n_iterations;
+    if (jobs64 > 0xFFFFFFF0ull) {
+        if (err) *err = "too many jobs in one launch";
+        return PTMI_ERR_INVALID_ARGUMENT;
+    }
+    const uint32_t n_jobs = (uint32_t)jobs64;
     hipError_t e = hipMemsetAsync(job_counter, 0, sizeof(uint32_t), (hipStream_t)stream);
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
         if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
-        hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel, dim3(blocks), dim3(ptmi_dev::kWfBlock),
-                           wavefront_lds_bytes(stack_levels), (hipStream_t)stream, sc, first_iteration, n_iterations,
-                           n_jobs, job_counter);
+        if (scheduler_stats)
+            hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel<true>, dim3(blocks), dim3(ptmi_dev::kWfBlock),
+                               wavefront_lds_bytes(stack_levels), (hipStream_t)stream, sc, first_iteration,
+                               n_iterations, n_jobs, job_counter, clamp_levels(stack_levels), stage);
+        else
+            hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel<false>, dim3(blocks), dim3(ptmi_dev::kWfBlock),
+                               wavefront_lds_bytes(stack_levels), (hipStream_t)stream, sc, first_iteration,
+                               n_iterations, n_jobs, job_counter, clamp_levels(stack_levels), stage);
         e = hipGetLastError();
+        if (e == hipSuccess && sc.sampler != PTMI_SAMPLER_RANDOM) {
+            const uint32_t n_pixels = sc.width * sc.height;
+            hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+                               (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
+            e = hipGetLastError();
+        }
     }
     if (e != hipSuccess) {
         if (err) *err = std::string("render_wavefront_kernel launch: ") + hipGetErrorString(e);

@@ -45,6 +45,8 @@ struct ptmi_ctx {
     uint32_t* d_hist = nullptr;  // depths | bbx | tri
     unsigned long long* d_counters = nullptr;
     uint32_t* d_job_counter = nullptr;
+    float* d_stage = nullptr;        // staged radiances [iteration][pixel] float4 of the launch in flight
+    size_t stage_iterations = 0;
     int resident_blocks = 0;
     uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     DScene ds{};
@@ -79,6 +81,9 @@ void free_scene_memory(ptmi_ctx* ctx)
     ctx->d_hist = nullptr;
     ctx->d_counters = nullptr;
     ctx->d_job_counter = nullptr;
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    ctx->d_stage = nullptr;
+    ctx->stage_iterations = 0;
     ctx->accum_bound = false;
     ctx->have_scene = false;
 }
@@ -405,12 +410,37 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
         HIP_TRY(ctx, hipEventCreate(&ev.first));
         HIP_TRY(ctx, hipEventCreate(&ev.second));
     }
+    const bool megakernel = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0;
+    if (!megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM) {
+        // staging array for the launch: grows on demand, capped by kMaxIterationsPerLaunch
+        const size_t want = n_iterations < kMaxIterationsPerLaunch ? n_iterations : kMaxIterationsPerLaunch;
+        if (want > ctx->stage_iterations) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+            ctx->d_stage = nullptr;
+            ctx->stage_iterations = 0;
+            const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, want * npix * 16));
+            ctx->d_stage = (float*)p;
+            ctx->stage_iterations = want;
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
     std::string err;
-    const int rc = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL)
-                       ? launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err)
-                       : launch_render_wavefront(ctx->ds, first_iteration, n_iterations, ctx->d_job_counter,
-                                                 ctx->resident_blocks, ctx->stack_levels, ctx->stream, &err);
+    int rc = PTMI_OK;
+    if (megakernel) {
+        rc = launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err);
+    } else {
+        // one launch per chunk of iterations; chunks run back to back on the stream, in order
+        for (uint32_t done = 0; done < n_iterations && rc == PTMI_OK;) {
+            const uint32_t n = n_iterations - done < kMaxIterationsPerLaunch ? n_iterations - done : kMaxIterationsPerLaunch;
+            rc = launch_render_wavefront(ctx->ds, first_iteration + done, n, ctx->d_job_counter, ctx->resident_blocks,
+                                         ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0,
+                                         ctx->d_stage, ctx->stream, &err);
+            done += n;
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
     ctx->pending_events.push_back(ev);
     if (rc) return fail(ctx, rc, err);

@@ -113,6 +113,10 @@ int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterati
 // stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30)
 int wavefront_resident_blocks(int device, uint32_t stack_levels);
 int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
-                            int resident_blocks, uint32_t stack_levels, void* stream, std::string* err);
+                            int resident_blocks, uint32_t stack_levels, bool scheduler_stats, float* stage,
+                            void* stream, std::string* err);
+
+// iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
+constexpr uint32_t kMaxIterationsPerLaunch = 16;
 
 }  // namespace ptmi_internal
