@@ -197,6 +197,16 @@ def camera(position, direction, right, up):
     return _f4(position, 1.0), _f4(direction, 0.0), _f4(right, 0.0), _f4(up, 0.0)
 
 
+def _records(items, dtype):
+    """Array of struct records with ZEROED padding bytes (np.array(list_of_records, dtype) leaves them undefined,
+    and scene files / digests should not depend on heap garbage)."""
+    out = np.zeros(len(items), dtype=dtype)
+    for i, it in enumerate(items):
+        for name in dtype.names:
+            out[name][i] = it[name]
+    return out
+
+
 def _quad(a, b, c, d):
     """two triangles a-b-c, a-c-d"""
     a, b, c, d = (np.asarray(v, f32) for v in (a, b, c, d))
@@ -223,8 +233,8 @@ def cornell_box(width, height):
     555-unit scale, z up.  The reference has no emissive materials: light comes from Light[] and sky only.
     """
     WHITE, RED, GREEN = 0, 1, 2
-    mats = np.array([material_create(color=(0.73, 0.73, 0.73, 0)), material_create(color=(0.65, 0.05, 0.05, 0)),
-                     material_create(color=(0.12, 0.45, 0.15, 0))], dtype=S.Material)
+    mats = _records([material_create(color=(0.73, 0.73, 0.73, 0)), material_create(color=(0.65, 0.05, 0.05, 0)),
+                     material_create(color=(0.12, 0.45, 0.15, 0))], S.Material)
     parts = []
 
     def add_quad(a, b, c, d, mat):
@@ -252,7 +262,7 @@ def cornell_box(width, height):
 
     tris = _concat_tris(parts)
     assert len(tris) == 32
-    lights = np.array([light_point((278.0, 279.5, 420.0), power=120000.0)], dtype=S.Light)
+    lights = _records([light_point((278.0, 279.5, 420.0), power=120000.0)], S.Light)
     sky, texels = no_sky()
     span = 0.75
     pos, d, r, u = camera((278.0, -800.0, 273.0), (0, 1, 0), (span, 0, 0), (0, 0, span * height / width))
@@ -271,8 +281,8 @@ def random_triangles(n, width, height, seed=12345):
     offs = rs.uniform(-0.1, 0.1, (n, 3, 3)).astype(f32)
     v = (centres[:, None, :] + offs).astype(f32)
     tris = triangle_create(v[:, 0], v[:, 1], v[:, 2], mat_pos=0)
-    mats = np.array([material_create(color=(0.7, 0.7, 0.7, 0))], dtype=S.Material)
-    lights = np.array([light_point((-9.0, 3.0, 6.0), power=60.0)], dtype=S.Light)
+    mats = _records([material_create(color=(0.7, 0.7, 0.7, 0))], S.Material)
+    lights = _records([light_point((-9.0, 3.0, 6.0), power=60.0)], S.Light)
     sky, texels = no_sky((200, 200, 200, 255))
     pos, d, r, u = camera((-14.0, 0.0, 0.0), (1, 0, 0), (0, 1, 0), (0, 0, height / width))
     return Scene(tris, lights, mats, np.zeros(0, S.Texture), texels, sky, pos, d, r, u, name=f"tris{n}",
@@ -362,7 +372,7 @@ def material_mix(width, height):
     t_wood = add_tex(_gradient(24, 8, (150, 90, 40), (220, 170, 90)), 24, 8)
 
     M = dict(floor=0, red=1, glass=2, water=3, varnish_tex=4, metal=5, varnish=6, blue=7, white=8)
-    mats = np.array([
+    mats = _records([
         material_create(S.MAT_STANDART, texture_id=t_check),
         material_create(S.MAT_STANDART, color=(0.8, 0.2, 0.15, 0)),
         material_create(S.MAT_GLASS, color=(0.9, 0.95, 1.0, 0), opacity=0.1),
@@ -372,7 +382,7 @@ def material_mix(width, height):
         material_create(S.MAT_VARNHISHED, color=(0.2, 0.6, 0.3, 0)),
         material_create(S.MAT_STANDART, color=(0.2, 0.3, 0.8, 0)),
         material_create(S.MAT_STANDART, color=(0.8, 0.8, 0.8, 0)),
-    ], dtype=S.Material)
+    ], S.Material)
 
     parts = []
     # textured floor, 8x8 quads with uv tiling
@@ -399,15 +409,15 @@ def material_mix(width, height):
     parts.append(triangle_create(s1, s2, s3, mat_pos=M["water"], mat_neg=M["water"]))
     tris = _concat_tris(parts)
 
-    lights = np.array([
+    lights = _records([
         light_point((3.0, -4.0, 6.0), color=(1, 0.95, 0.9, 1), power=40.0),
         light_spot((-4.0, -4.0, 7.0), (0.5, 0.6, -1.0), cone_angle=0.7, penumbra_angle=0.3, color=(0.9, 0.9, 1, 1),
                    intensity=1.5),
         light_directional((-0.3, 0.4, -1.0), color=(1, 1, 0.9, 1), power=0.6),
-    ], dtype=S.Light)
+    ], S.Light)
     span = 0.9
     pos, d, r, u = camera((0.5, -11.0, 3.5), (0, 1, -0.22), (span, 0, 0), (0, 0.22 * span * height / width, span * height / width))
-    return Scene(tris, lights, mats, np.array(textures, dtype=S.Texture), np.concatenate(texels), sky, pos, d, r, u,
+    return Scene(tris, lights, mats, np.array(textures, dtype=S.Texture) if textures else np.zeros(0, S.Texture), np.concatenate(texels), sky, pos, d, r, u,
                  name="matmix")
 
 

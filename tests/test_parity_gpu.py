@@ -89,6 +89,71 @@ def test_edge_sizes_and_depth_zero(kernel, scene_factory):
         assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and counters == totals, (w, h, d)
 
 
+def _custom_scene(tris, base):
+    import copy
+    from opencl_pathtracer_amd import bvh_create
+    sc = copy.copy(base)
+    sc.triangulation = tris
+    sc.bvh = None
+    return bvh_create(sc)
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_degenerate_trees_and_big_leaves(kernel, scene_factory):
+    """Root that is a leaf (<= 4 triangles), and a leaf of 40 coincident triangles (NODE_LEAF_MIN_DIAG): the
+    reference puts no bound on a leaf's size; the device layout keeps such leaves in a side table."""
+    from opencl_pathtracer_amd import scenes
+    base = scenes.cornell_box(48, 32)
+    rs = np.random.RandomState(5)
+    few = (rs.uniform(100, 450, (3, 1, 3)) + rs.uniform(-120, 120, (3, 3, 3))).astype(np.float32)
+    one_leaf = _custom_scene(scenes.triangle_create(few[:, 0], few[:, 1], few[:, 2]), base)
+    assert len(one_leaf.bvh) == 1 and one_leaf.bvh["isLeaf"][0]
+    tri0 = (np.array([[[150, 200, 100], [420, 230, 120], [260, 300, 420]]], np.float32))
+    stack = np.repeat(tri0, 40, axis=0) + rs.uniform(-1e-3, 1e-3, (40, 3, 3)).astype(np.float32)
+    wall = scenes.cornell_box(48, 32).triangulation[:10]
+    big = scenes.triangle_create(stack[:, 0], stack[:, 1], stack[:, 2])
+    both = scenes._concat_tris([wall.copy(), big])
+    big_leaf = _custom_scene(both, base)
+    assert big_leaf.bvh["nbTriangles"][big_leaf.bvh["isLeaf"] != 0].max() > 6
+    for sc in (one_leaf, big_leaf):
+        color, count, (dep, bbx, tri), counters = render_scene(sc, 48, 32, 4, 3, flags=KERNELS[kernel])
+        o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 48, 32, 4, 3)
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and counters == totals
+        assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_unconventional_w_components(kernel, scene_factory):
+    """OpenCL's dot/normalize are 4-component: scenes whose w lanes break the importer's conventions (points
+    w=1, N.w=1, normals w=0) must still equal the reference algorithm, which the oracle evaluates literally."""
+    import copy
+    sc = copy.copy(scene_factory("matmix", 96, 96))
+    t = sc.triangulation.copy()
+    rs = np.random.RandomState(11)
+    t["N"][:, 3] = rs.uniform(-0.5, 1.5, len(t)).astype(np.float32)
+    t["S1"][:, 3] = 1.0 + rs.uniform(-0.05, 0.05, len(t)).astype(np.float32)
+    t["S3"][:, 3] = 1.0 + rs.uniform(-0.05, 0.05, len(t)).astype(np.float32)
+    t["N2"][:, 3] = rs.uniform(-0.2, 0.2, len(t)).astype(np.float32)
+    sc.triangulation = t
+    sc.cameraDirection = sc.cameraDirection.copy()
+    sc.cameraDirection[3] = 0.05
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 96, 96, 8, 3, flags=KERNELS[kernel])
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 96, 96, 8, 3)
+    assert counters == totals and np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx)
+    same = color.view(np.uint32) == o_color.view(np.uint32)
+    nan_both = np.isnan(color) & np.isnan(o_color)
+    assert (same | nan_both).all()
+
+
+def test_many_iterations_in_one_call_are_chunked(scene_factory):
+    """ptmi_render splits a long range into launches of <= 16 iterations (staging array bound): same bits."""
+    sc = scene_factory("cornell", 64, 48)
+    color, count, (dep, _, _), counters = render_scene(sc, 64, 48, 4, 37)
+    o_color, o_count, (o_dep, _, _), totals = O.oracle_render(sc, 64, 48, 4, 37)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and (count == 37).all()
+    assert np.array_equal(dep, o_dep) and counters == totals
+
+
 def test_clear_and_reinitialize(scene_factory):
     sc = scene_factory("cornell", 64, 48)
     be = Backend().setup_context(64, 48, 4, 1)

@@ -1,0 +1,54 @@
+"""Scene-cache files in the reference's format (PathTracer_FileImporter.cpp:16-147): byte layout and round trip."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from opencl_pathtracer_amd import scenes, scene_cache, bvh_create, structs as S
+
+
+def test_file_layout_is_the_reference_format(tmp_path, built):
+    sc = scenes.material_mix(32, 32)
+    scene_cache.export_scene(sc, str(tmp_path))
+    sizes = open(tmp_path / "sizes.pth", "rb").read()
+    assert len(sizes) == 4 * 16 + 5 * 4
+    # order in the file: direction, right, up, position (FileImporter.cpp:27-30), then the five counts (:32-36)
+    assert np.array_equal(np.frombuffer(sizes, np.float32, 4, 0), sc.cameraDirection)
+    assert np.array_equal(np.frombuffer(sizes, np.float32, 4, 48), sc.cameraPosition)
+    assert struct.unpack_from("<5I", sizes, 64) == (len(sc.triangulation), 3, len(sc.materiaux), 2, len(sc.texturesData))
+    ptr = os.path.getsize(tmp_path / "pointers.pth")
+    assert ptr == len(sc.triangulation) * 336 + 3 * 64 + len(sc.materiaux) * 48 + 2 * 12 + 92
+    assert os.path.getsize(tmp_path / "textureData.pth") == 4 * len(sc.texturesData)
+    first = np.frombuffer(open(tmp_path / "pointers.pth", "rb").read(), S.Triangle, 1)[0]
+    assert first.tobytes() == sc.triangulation[0].tobytes()
+
+
+def test_round_trip_renders_identically(tmp_path, built):
+    sc = scenes.material_mix(48, 48)
+    scene_cache.export_scene(sc, str(tmp_path / "ExportedScene"))
+    back = scene_cache.import_scene(str(tmp_path / "ExportedScene"))
+    ref = bvh_create(scenes.material_mix(48, 48))
+    for name in ("triangulation", "lights", "materiaux", "textures", "texturesData", "bvh"):
+        assert np.ascontiguousarray(getattr(back, name)).tobytes() == np.ascontiguousarray(getattr(ref, name)).tobytes(), name
+    assert back.sky.tobytes() == ref.sky.tobytes() and back.bvhMaxDepth == ref.bvhMaxDepth
+    a = O.oracle_render(back, 48, 48, 5, 2)
+    b = O.oracle_render(ref, 48, 48, 5, 2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2][0], b[2][0])
+
+
+def test_load_sky_false_and_errors(tmp_path, built):
+    sc = scenes.cornell_box(16, 16)
+    scene_cache.export_scene(sc, str(tmp_path))
+    nosky = scene_cache.import_scene(str(tmp_path), load_sky=False, build_bvh=False)
+    assert len(nosky.texturesData) == 1 and not nosky.texturesData.any() and nosky.sky["cosRotationAngle"] == 1
+    assert all(tuple(t) == (1, 1, 0) for t in nosky.sky["skyTextures"])
+    os.remove(tmp_path / "textureData.pth")
+    with pytest.raises(RuntimeError, match="Fail to read the files to import"):
+        scene_cache.import_scene(str(tmp_path))
+    scene_cache.export_scene(sc, str(tmp_path))
+    with open(tmp_path / "pointers.pth", "r+b") as f:
+        f.truncate(1000)
+    with pytest.raises(RuntimeError, match="truncated"):
+        scene_cache.import_scene(str(tmp_path))
