@@ -145,7 +145,8 @@ def bvh_create(scene):
     if rc:
         raise PtmiError(rc, lib.ptmi_last_error(None).decode())
     scene.triangulation = tris
-    scene.bvh = nodes[:size.value].copy()
+    # byte-level copy (numpy's .copy() of a padded struct dtype leaves the padding bytes undefined)
+    scene.bvh = np.frombuffer(bytearray(nodes[:size.value].tobytes()), dtype=S.Node)
     scene.bvhMaxDepth = depth.value
     return scene
 
