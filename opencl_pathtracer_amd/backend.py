@@ -294,9 +294,10 @@ class Backend:
 
 
 def render_scene(scene, width, height, ray_max_depth, n_iterations, first_iteration=0, sampler=S.JITTERED, device=0,
-                 flags=0):
+                 flags=0, super_sampling=False):
     """Convenience used by tests/bench: full life cycle for one iteration range."""
-    be = Backend().setup_context(width, height, ray_max_depth, scene.lightsSize, sampler, device=device, flags=flags)
+    be = Backend().setup_context(width, height, ray_max_depth, scene.lightsSize, sampler, super_sampling=super_sampling,
+                                 device=device, flags=flags)
     try:
         be.initialize_memory(scene)
         be.render(first_iteration, n_iterations)

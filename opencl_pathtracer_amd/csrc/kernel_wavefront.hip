@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             // JITTERED / UNIFORM: the sample lands on the work-item's own pixel (:1333-1336); stage it
             const size_t slot = (size_t)(it - first_iteration) * ((size_t)sc.width * sc.height) + (size_t)gy * sc.width + gx;
             reinterpret_cast<float4*>(stage)[slot] = make_float4(radiance.x, radiance.y, radiance.z, radiance.w);
+            if (sc.super_sampling) sc.stage_flag[slot] = 1.f;
         } else {
             // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345)
             const uint32_t off = sample_pixel(sc, sample_x, sample_y);
@@ -286,6 +287,22 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     shadow = false;
                     found = false;
                     need_path = false;
+                    bool skip = false;
+                    if (sc.super_sampling && it > 5u) {
+                        // superSamplingStopCriteria, FullKernel.cl:1152-1172 (called at :1219-1222, one launch per
+                        // iteration so the accumulators hold iterations < it); draws one random number
+                        const uint32_t off = gy * sc.width + gx;
+                        const float n = sc.image_ray_nb[off];
+                        const float4 vv = reinterpret_cast<const float4*>(sc.image_v)[off];
+                        const float sigma2_n = fmaxf(fmaxf(vv.x / n, vv.y / n), vv.z / n);
+                        uint32_t idx = (uint32_t)n;
+                        if (idx > 1000u) idx = 1000u;  // the reference indexes past its 1001-entry table here
+                        skip = (double)lcg_random(seed) > (double)(100 * sigma2_n / sc.x2inv[idx]) + 0.05;
+                    }
+                    if (skip) {
+                        sc.stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
+                        need_path = true;
+                    } else
                     if (sc.max_depth > 0) {
                         limit = INFINITY;
                         start_query();
@@ -388,6 +405,36 @@ __global__ void __launch_bounds__(256) accumulate_staged_kernel(float* __restric
     image_ray_nb[p] = count;
 }
 
+// SUPER_SAMPLING form of the accumulation (one iteration per launch): pixels whose path was skipped are left
+// alone; the others also update the variance accumulator imageV exactly as FullKernel.cl:1346-1349.
+__global__ void __launch_bounds__(256) accumulate_staged_ss_kernel(float* __restrict__ image_color,
+                                                                    float* __restrict__ image_ray_nb,
+                                                                    float* __restrict__ image_v,
+                                                                    const float* __restrict__ stage,
+                                                                    const float* __restrict__ stage_flag,
+                                                                    const uint32_t n_pixels, const uint32_t iteration)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    if (stage_flag[p] == 0.f) return;
+    const float4 before = reinterpret_cast<const float4*>(image_color)[p];
+    const float4 r = reinterpret_cast<const float4*>(stage)[p];
+    const float4 after = make_float4(before.x + r.x, before.y + r.y, before.z + r.z, before.w + r.w);
+    const float n_before = image_ray_nb[p];
+    const float n_after = n_before + 1.f;
+    image_ray_nb[p] = n_after;
+    reinterpret_cast<float4*>(image_color)[p] = after;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (iteration != 0) {
+        v = reinterpret_cast<const float4*>(image_v)[p];
+        v.x = v.x + (r.x - before.x / n_before) * (r.x - after.x / n_after);
+        v.y = v.y + (r.y - before.y / n_before) * (r.y - after.y / n_after);
+        v.z = v.z + (r.z - before.z / n_before) * (r.z - after.z / n_after);
+        v.w = v.w + (r.w - before.w / n_before) * (r.w - after.w / n_after);
+    }
+    reinterpret_cast<float4*>(image_v)[p] = v;
+}
+
 }  // namespace ptmi_dev
 
 namespace ptmi_internal {
@@ -448,8 +495,13 @@ int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t
         e = hipGetLastError();
         if (e == hipSuccess && sc.sampler != PTMI_SAMPLER_RANDOM) {
             const uint32_t n_pixels = sc.width * sc.height;
-            hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
-                               (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
+            if (sc.super_sampling)
+                hipLaunchKernelGGL(ptmi_dev::accumulate_staged_ss_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+                                   (hipStream_t)stream, sc.image_color, sc.image_ray_nb, sc.image_v, stage,
+                                   sc.stage_flag, n_pixels, first_iteration);
+            else
+                hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+                                   (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
             e = hipGetLastError();
         }
     }

@@ -19,6 +19,9 @@
 using namespace ptmi_internal;
 
 namespace {
+const float kX2inv[1001] = {
+#include "x2inv_table.inc"
+};
 std::mutex g_err_mutex;
 std::string g_err;  // failures that have no context yet
 }  // namespace
@@ -278,8 +281,9 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
     if (cfg->sampler > PTMI_SAMPLER_UNIFORM) return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "unknown sampler");
     if (cfg->lights_size >= PTMI_MAX_LIGHT_SIZE)  // PathTracer.cpp:60-65
         return fail(nullptr, PTMI_ERR_LIMIT, "lights_size >= 30");
-    if (cfg->super_sampling)
-        return fail(nullptr, PTMI_ERR_UNSUPPORTED, "SUPER_SAMPLING (adaptive sampling) is not built into this version");
+    if (cfg->super_sampling && (cfg->sampler == PTMI_SAMPLER_RANDOM || (cfg->flags & PTMI_FLAG_MEGAKERNEL)))
+        return fail(nullptr, PTMI_ERR_UNSUPPORTED,
+                    "SUPER_SAMPLING needs a sampler that owns its pixel (JITTERED/UNIFORM) and the wavefront kernel");
 
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -357,6 +361,15 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     ds.hist_bbx = hist ? ctx->d_hist + ctx->cfg.ray_max_depth + 1 : nullptr;
     ds.hist_tri = hist ? ctx->d_hist + ctx->cfg.ray_max_depth + 1 + PTMI_MAX_INTERSECTION_NUMBER : nullptr;
     ds.counters = ctx->d_counters;
+    ds.super_sampling = ctx->cfg.super_sampling ? 1u : 0u;
+    if (ds.super_sampling) {
+        void *dv = nullptr, *dx = nullptr, *df = nullptr;
+        HIP_TRY(ctx, hipMalloc(&dv, npix * 16)); ctx->allocations.push_back(dv);
+        HIP_TRY(ctx, hipMalloc(&dx, sizeof kX2inv)); ctx->allocations.push_back(dx);
+        HIP_TRY(ctx, hipMalloc(&df, npix * 4)); ctx->allocations.push_back(df);
+        HIP_TRY(ctx, hipMemcpy(dx, kX2inv, sizeof kX2inv, hipMemcpyHostToDevice));
+        ds.image_v = (float*)dv; ds.x2inv = (const float*)dx; ds.stage_flag = (float*)df;
+    }
     ds.sky = *sc->sky;
     std::memcpy(ds.cam_pos, &sc->camera_position, 16);
     std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
@@ -389,6 +402,7 @@ int ptmi_clear(ptmi_ctx* ctx)
     HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_ray_nb, 0, npix * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist, 0, hist_words * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * 8, ctx->stream));
+    if (ctx->ds.image_v) HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_v, 0, npix * 16, ctx->stream));
     return PTMI_OK;
 }
 
@@ -434,7 +448,9 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
     } else {
         // one launch per chunk of iterations; chunks run back to back on the stream, in order
         for (uint32_t done = 0; done < n_iterations && rc == PTMI_OK;) {
-            const uint32_t n = n_iterations - done < kMaxIterationsPerLaunch ? n_iterations - done : kMaxIterationsPerLaunch;
+            // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
+            const uint32_t cap = ctx->cfg.super_sampling ? 1u : kMaxIterationsPerLaunch;
+            const uint32_t n = n_iterations - done < cap ? n_iterations - done : cap;
             rc = launch_render_wavefront(ctx->ds, first_iteration + done, n, ctx->d_job_counter, ctx->resident_blocks,
                                          ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0,
                                          ctx->d_stage, ctx->stream, &err);

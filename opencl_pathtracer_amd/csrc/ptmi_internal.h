@@ -97,6 +97,9 @@ struct DScene {
     uint32_t* hist_bbx;     // [5000]
     uint32_t* hist_tri;     // [5000]
     unsigned long long* counters;  // [C_COUNT]
+    float* image_v;                // float4[W*H] global__imageV, only with SUPER_SAMPLING
+    const float* x2inv;            // 1001-entry table, only with SUPER_SAMPLING
+    float* stage_flag;             // float[W*H] per launch: 1 = path traced, 0 = skipped by the stop criterion
     ptmi_sky sky;
     float cam_pos[4], cam_dir[4], cam_right[4], cam_up[4];
     uint32_t root_ref;
@@ -104,6 +107,7 @@ struct DScene {
     uint32_t max_depth;  // MAX_REFLECTION_NUMBER
     uint32_t n_lights;   // LIGHTS_SIZE
     uint32_t sampler;
+    uint32_t super_sampling;  // -D SUPER_SAMPLING
 };
 
 // kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)

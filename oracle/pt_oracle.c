@@ -650,7 +650,11 @@ static int super_sampling_stop(const pto_scene* sc, const pto_buffers* out, cons
     sy = out->image_v[4 * off + 1] / n;
     sz = out->image_v[4 * off + 2] / n;
     sigma2_n = fmaxf(fmaxf(sx, sy), sz);
-    return (double)pto_random(seed) > (double)(100 * sigma2_n / sc->x2inv[(uint32_t)n]) + 0.05;
+    {
+        uint32_t idx = (uint32_t)n;
+        if (idx > 1000u) idx = 1000u; /* the reference reads past its 1001-entry table for n > 1000 (no clamp) */
+        return (double)pto_random(seed) > (double)(100 * sigma2_n / sc->x2inv[idx]) + 0.05;
+    }
 }
 
 /* ------------------------------------------------------------------------- */

@@ -108,10 +108,18 @@ def _f4(v):
     return F4(float(v[0]), float(v[1]), float(v[2]), float(v[3]))
 
 
+def x2inv_table():
+    """The adaptive sampler's table, computed here from its definition (chi2.ppf(0.01, n), six decimals) --
+    independently of the product's generated x2inv_table.inc."""
+    from scipy.stats import chi2
+    t = np.concatenate([[0.0], chi2.ppf(0.01, np.arange(1, 1001))])
+    return np.round(t, 6).astype(np.float32)
+
+
 class OracleScene:
     """Keeps the numpy arrays alive next to the C struct that points into them."""
 
-    def __init__(self, scene, width, height, ray_max_depth, sampler=S.JITTERED):
+    def __init__(self, scene, width, height, ray_max_depth, sampler=S.JITTERED, super_sampling=False):
         self.arrays = [np.ascontiguousarray(a) for a in (scene.bvh, scene.triangulation, scene.lights, scene.materiaux,
                                                          scene.textures, scene.texturesData, scene.sky)]
         s = PtoScene()
@@ -121,16 +129,19 @@ class OracleScene:
         s.camera_right, s.camera_up = _f4(scene.cameraRight), _f4(scene.cameraUp)
         s.image_width, s.image_height, s.ray_max_depth = width, height, ray_max_depth
         s.lights_size, s.sampler, s.super_sampling, s.x2inv = len(scene.lights), sampler, 0, None
+        if super_sampling:
+            self.x2inv = x2inv_table()
+            s.super_sampling, s.x2inv = 1, self.x2inv.ctypes.data_as(C.c_void_p)
         self.c = s
         self.width, self.height, self.depth = width, height, ray_max_depth
 
 
 def oracle_render(scene, width, height, ray_max_depth, n_iterations, first_iteration=0, sampler=S.JITTERED,
-                  n_threads=8, into=None):
+                  n_threads=8, into=None, super_sampling=False, image_v=None):
     """Returns (imageColor[H,W,4], imageRayNb[H,W], (depths, bbx, tri), totals dict).  `into` = a previous
     result tuple to keep accumulating into (iteration ranges must then be rendered in order)."""
     lib = oracle()
-    osc = OracleScene(scene, width, height, ray_max_depth, sampler)
+    osc = OracleScene(scene, width, height, ray_max_depth, sampler, super_sampling)
     if into is None:
         color = np.zeros((height, width, 4), np.float32)
         count = np.zeros((height, width), np.float32)
@@ -139,7 +150,7 @@ def oracle_render(scene, width, height, ray_max_depth, n_iterations, first_itera
         tri = np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32)
     else:
         color, count, (depths, bbx, tri), _ = into
-    imgv = np.zeros((height, width, 4), np.float32)
+    imgv = np.zeros((height, width, 4), np.float32) if image_v is None else image_v
     buf = PtoBuffers(_vp(color), _vp(count), _vp(imgv), _vp(depths), _vp(bbx), _vp(tri))
     tot = PtoTotals()
     lib.pto_render(C.byref(osc.c), first_iteration, n_iterations, C.byref(buf), n_threads, C.byref(tot))
