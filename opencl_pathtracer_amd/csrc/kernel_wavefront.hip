@@ -34,6 +34,8 @@
 #include "ptmi_device.hpp"
 #include "ptmi_shading.hpp"
 
+#include <cstring>
+
 namespace ptmi_dev {
 
 constexpr int kWfBlock = 256;
@@ -46,7 +48,27 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #endif
 constexpr int kPostThreshold = PTMI_WF_POST_THRESHOLD;  // lanes waiting for path logic before the wave spends a trip on it
 
-__device__ __forceinline__ void decode_leaf(const DScene& sc, uint32_t ref, uint32_t& tri_i, uint32_t& tri_end)
+// Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
+// rest of DScene (sky: only when a path escapes; histogram / RANDOM-sampler / SUPER_SAMPLING buffers; counters)
+// is read from a device-memory copy where it is used.  Measured on MI355X: the whole DScene by value (~80 SGPRs)
+// spills SGPRs into the hot loop; everything through memory stalls each path-logic trip on ~50 scalar loads
+// (-4.5 %); this split is the fastest of the three.
+struct DWarm {
+    const DNode* nodes;
+    const DTri* tris;
+    const DBigLeaf* big_leaves;
+    const DShade* shade;
+    const DMat* mats;
+    const ptmi_light* lights;
+    const ptmi_texture* textures;
+    const ptmi_uchar4* texels;
+    uint32_t root_ref;
+    uint32_t width, height;
+    uint32_t max_depth, n_lights, sampler, tris_precomputed;
+    uint32_t histograms;  // hist_depths != nullptr
+};
+
+__device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint32_t& tri_i, uint32_t& tri_end)
 {
     uint32_t count = (ref >> REF_COUNT_SHIFT) & 7u;
     uint32_t start = ref & REF_INDEX_MASK_LEAF;
@@ -59,8 +81,9 @@ __device__ __forceinline__ void decode_leaf(const DScene& sc, uint32_t ref, uint
     tri_end = start + count;
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(const DScene sc, const uint32_t first_iteration,
+template <bool STATS, bool PRE, bool SS>
+__global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(
+                                                                    const DScene* __restrict__ scene_in_memory, const DWarm sc, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t n_jobs,
                                                                     uint32_t* __restrict__ job_counter,
                                                                     const uint32_t stack_levels,
@@ -79,6 +102,12 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     if (tid < C_COUNT) block_counters[tid] = 0;
     __syncthreads();
     uint32_t* const stack = &stack_mem[tid];
+    // the rare fields: pointer re-derived through an opaque asm so the loads stay where they are used
+    auto cold_scene = [&]() -> const DScene& {
+        const DScene* p = scene_in_memory;
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
     // The closest-hit record (point, s, t, triangle, side) changes only when a closer hit is accepted and is read
     // only by path logic: it lives in LDS behind the stack, [field][lane], not in registers of the hot loop.
 #ifdef PTMI_WF_STATIC_STACK
@@ -136,24 +165,26 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // statistics + accumulation of a finished path (FullKernel.cl:1319-1345)
     auto finish_path = [&]() {
         n_bbx += p_bbx; n_tri += p_tri; n_hits += reflection; n_paths++;
-        if (sc.hist_depths) {
-            atomicAdd(&sc.hist_depths[reflection], 1u);
-            if (p_bbx < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_bbx[p_bbx], 1u);
-            if (p_tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[p_tri], 1u);
+        if (sc.histograms) {
+            const DScene& cs = cold_scene();
+            atomicAdd(&cs.hist_depths[reflection], 1u);
+            if (p_bbx < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&cs.hist_bbx[p_bbx], 1u);
+            if (p_tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&cs.hist_tri[p_tri], 1u);
         }
         if (owns_pixel) {
             // JITTERED / UNIFORM: the sample lands on the work-item's own pixel (:1333-1336); stage it
             const size_t slot = (size_t)(it - first_iteration) * ((size_t)sc.width * sc.height) + (size_t)gy * sc.width + gx;
             reinterpret_cast<float4*>(stage)[slot] = make_float4(radiance.x, radiance.y, radiance.z, radiance.w);
-            if (sc.super_sampling) sc.stage_flag[slot] = 1.f;
+            if (SS) cold_scene().stage_flag[slot] = 1.f;
         } else {
             // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345)
             const uint32_t off = sample_pixel(sc, sample_x, sample_y);
-            atomicAdd(&sc.image_color[4 * off + 0], radiance.x);
-            atomicAdd(&sc.image_color[4 * off + 1], radiance.y);
-            atomicAdd(&sc.image_color[4 * off + 2], radiance.z);
-            atomicAdd(&sc.image_color[4 * off + 3], radiance.w);
-            atomicAdd(&sc.image_ray_nb[off], 1.f);
+            const DScene& cs = cold_scene();
+            atomicAdd(&cs.image_color[4 * off + 0], radiance.x);
+            atomicAdd(&cs.image_color[4 * off + 1], radiance.y);
+            atomicAdd(&cs.image_color[4 * off + 2], radiance.z);
+            atomicAdd(&cs.image_color[4 * off + 3], radiance.w);
+            atomicAdd(&cs.image_ray_nb[off], 1.f);
         }
         need_path = true;
         cur = REF_NONE; tri_i = tri_end = 0;
@@ -205,7 +236,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                             if (sc.n_lights > 0) start_shadow = true;
                             else do_scatter = true;
                         } else {
-                            radiance = radiance + (sky_color(sc.sky, sc.texels, r.d) * transfer);
+                            radiance = radiance + (sky_color(cold_scene().sky, sc.texels, r.d) * transfer);
                             end_path = true;
                         }
                     } else {
@@ -278,8 +309,11 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 if (got_job) {
                     seed = lcg_seed(gx, gy, sc.width, sc.height, it);
                     draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
-                    r.o = v4(sc.cam_pos);
-                    ray_set_direction(r, (v4(sc.cam_dir) + (v4(sc.cam_right) * sample_x)) + (v4(sc.cam_up) * sample_y));
+                    {
+                        const DScene& cs = cold_scene();  // camera: only needed here, once per path
+                        r.o = v4(cs.cam_pos);
+                        ray_set_direction(r, (v4(cs.cam_dir) + (v4(cs.cam_right) * sample_x)) + (v4(cs.cam_up) * sample_y));
+                    }
                     radiance = v4(0, 0, 0, 0);
                     transfer = v4(1, 1, 1, 1);
                     reflection = 0; p_bbx = 0; p_tri = 0;
@@ -288,19 +322,20 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     found = false;
                     need_path = false;
                     bool skip = false;
-                    if (sc.super_sampling && it > 5u) {
+                    if (SS && it > 5u) {
                         // superSamplingStopCriteria, FullKernel.cl:1152-1172 (called at :1219-1222, one launch per
                         // iteration so the accumulators hold iterations < it); draws one random number
+                        const DScene& cs = cold_scene();
                         const uint32_t off = gy * sc.width + gx;
-                        const float n = sc.image_ray_nb[off];
-                        const float4 vv = reinterpret_cast<const float4*>(sc.image_v)[off];
+                        const float n = cs.image_ray_nb[off];
+                        const float4 vv = reinterpret_cast<const float4*>(cs.image_v)[off];
                         const float sigma2_n = fmaxf(fmaxf(vv.x / n, vv.y / n), vv.z / n);
                         uint32_t idx = (uint32_t)n;
                         if (idx > 1000u) idx = 1000u;  // the reference indexes past its 1001-entry table here
-                        skip = (double)lcg_random(seed) > (double)(100 * sigma2_n / sc.x2inv[idx]) + 0.05;
+                        skip = (double)lcg_random(seed) > (double)(100 * sigma2_n / cs.x2inv[idx]) + 0.05;
                     }
                     if (skip) {
-                        sc.stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
+                        cold_scene().stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
                         need_path = true;
                     } else
                     if (sc.max_depth > 0) {
@@ -328,7 +363,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
                     Hit h;
                     p_tri++;
-                    if (tri_hit(v4(a), v4(b), v4(c), v4(d), r, limit, h)) {
+                    if (tri_hit_record<PRE>(a, b, c, d, r, limit, h)) {
                         found = true;
                         if (shadow) {  // any hit ends a shadow query (:724-727)
                             tri_end = tri_i;
@@ -382,7 +417,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         atomicAdd(&block_counters[C_LANES_P], lanes_p);
     }
     __syncthreads();
-    if (tid < C_COUNT) atomicAdd(&sc.counters[tid], block_counters[tid]);
+    if (tid < C_COUNT) atomicAdd(&cold_scene().counters[tid], block_counters[tid]);
 }
 
 // Adds the staged radiances of one launch to the accumulators, per pixel in iteration order:
@@ -461,16 +496,16 @@ int wavefront_resident_blocks(int device, uint32_t stack_levels)
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel<false>, ptmi_dev::kWfBlock,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel<false, true, false>, ptmi_dev::kWfBlock,
                                                      wavefront_lds_bytes(stack_levels)) != hipSuccess)
         return 0;
     if (per_cu < 1) per_cu = 1;
     return per_cu * prop.multiProcessorCount;
 }
 
-int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
-                            int resident_blocks, uint32_t stack_levels, bool scheduler_stats, float* stage,
-                            void* stream, std::string* err)
+int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
+                            uint32_t n_iterations, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
+                            bool scheduler_stats, float* stage, void* stream, std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
     const uint32_t tiles = ((sc.width + 7u) / 8u) * ((sc.height + 7u) / 8u);
@@ -484,14 +519,30 @@ int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
         if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
-        if (scheduler_stats)
-            hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel<true>, dim3(blocks), dim3(ptmi_dev::kWfBlock),
-                               wavefront_lds_bytes(stack_levels), (hipStream_t)stream, sc, first_iteration,
-                               n_iterations, n_jobs, job_counter, clamp_levels(stack_levels), stage);
-        else
-            hipLaunchKernelGGL(ptmi_dev::render_wavefront_kernel<false>, dim3(blocks), dim3(ptmi_dev::kWfBlock),
-                               wavefront_lds_bytes(stack_levels), (hipStream_t)stream, sc, first_iteration,
-                               n_iterations, n_jobs, job_counter, clamp_levels(stack_levels), stage);
+        const dim3 g(blocks), b(ptmi_dev::kWfBlock);
+        const size_t lds = wavefront_lds_bytes(stack_levels);
+        const uint32_t lv = clamp_levels(stack_levels);
+        hipStream_t st = (hipStream_t)stream;
+        ptmi_dev::DWarm warm{};
+        warm.nodes = sc.nodes; warm.tris = sc.tris; warm.big_leaves = sc.big_leaves; warm.shade = sc.shade;
+        warm.mats = sc.mats; warm.lights = sc.lights; warm.textures = sc.textures; warm.texels = sc.texels;
+        warm.root_ref = sc.root_ref; warm.width = sc.width; warm.height = sc.height; warm.max_depth = sc.max_depth;
+        warm.n_lights = sc.n_lights; warm.sampler = sc.sampler; warm.tris_precomputed = sc.tris_precomputed;
+        warm.histograms = sc.hist_depths != nullptr;
+#define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
+    hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
+                       first_iteration, n_iterations, n_jobs, job_counter, lv, stage)
+#define PTMI_LAUNCH_WF(S, P, A)                                                                                       \
+    PTMI_LAUNCH_WF_IMPL(S, P, A)
+        // instantiations: the common case (no statistics, no adaptive sampling) pays for neither
+        if (sc.super_sampling) {
+            if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, true); else PTMI_LAUNCH_WF(true, false, true);
+        } else if (scheduler_stats) {
+            if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false); else PTMI_LAUNCH_WF(true, false, false);
+        } else {
+            if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false); else PTMI_LAUNCH_WF(false, false, false);
+        }
+#undef PTMI_LAUNCH_WF
         e = hipGetLastError();
         if (e == hipSuccess && sc.sampler != PTMI_SAMPLER_RANDOM) {
             const uint32_t n_pixels = sc.width * sc.height;

@@ -33,7 +33,7 @@ struct PathCounters {
 // (dir[cutAxis] > 0 ? son1 : son2) is tested first and descended first, the
 // other is pushed; leaf triangles in ascending index with the distance limit
 // updated between tests.
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool PRE>
 __device__ __forceinline__ bool traverse(const DScene& sc, const Ray& r, float limit, Hit& hit, PathCounters& pc,
                                          uint32_t* __restrict__ stack)
 {
@@ -51,7 +51,8 @@ __device__ __forceinline__ bool traverse(const DScene& sc, const Ray& r, float l
             }
             for (uint32_t i = start; i < start + count; i++) {
                 pc.tri++;
-                if (tri_hit(&sc.tris[i], r, limit, hit)) {
+                const float4* q4 = reinterpret_cast<const float4*>(&sc.tris[i]);
+                if (tri_hit_record<PRE>(q4[0], q4[1], q4[2], q4[3], r, limit, hit)) {
                     if (ANY_HIT) return true;
                     hit.tri = i;
                     found = true;
@@ -88,6 +89,7 @@ __device__ __forceinline__ bool traverse(const DScene& sc, const Ray& r, float l
 
 // One path = one Kernel_Main work-item (FullKernel.cl:1180-1331) up to the
 // statistics; returns the radiance and the sample position.
+template <bool PRE>
 __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t gy, uint32_t iteration,
                                          uint32_t* __restrict__ stack, float& sample_x, float& sample_y,
                                          uint32_t& depth, uint32_t& segments, uint32_t& shadows, PathCounters& pc)
@@ -109,7 +111,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
         Hit hit;
         hit.tri = 0; hit.s = 0; hit.t = 0; hit.front = false; hit.point = v4(0, 0, 0, 0);
         segments++;
-        if (traverse<false>(sc, r, INFINITY, hit, pc, stack)) {
+        if (traverse<false, PRE>(sc, r, INFINITY, hit, pc, stack)) {
             Surface sf;
             load_surface(sc, r, hit, sf);
 
@@ -126,7 +128,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
                 const float brdf = material_brdf(sf.mat.type, -lr.d, sf.Ns, r.d);
                 Hit dummy;
                 shadows++;
-                if (!traverse<true>(sc, lr, light_distance, dummy, pc, stack))
+                if (!traverse<true, PRE>(sc, lr, light_distance, dummy, pc, stack))
                     direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
             }
 
@@ -146,6 +148,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
     return radiance;
 }
 
+template <bool PRE>
 __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const uint32_t first_iteration,
                                                         const uint32_t n_iterations)
 {
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const u
             float sx, sy;
             uint32_t depth;
             PathCounters pc;
-            const V4 radiance = trace_path(sc, gx, gy, it, stack, sx, sy, depth, n_seg, n_shadow, pc);
+            const V4 radiance = trace_path<PRE>(sc, gx, gy, it, stack, sx, sy, depth, n_seg, n_shadow, pc);
             n_bbx += pc.bbx;
             n_tri += pc.tri;
             n_hits += depth;
@@ -224,8 +227,12 @@ int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterati
 {
     if (n_iterations == 0) return PTMI_OK;
     const dim3 grid((sc.width + 15u) / 16u, (sc.height + 15u) / 16u);
-    hipLaunchKernelGGL(ptmi_dev::render_kernel, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
-                       first_iteration, n_iterations);
+    if (sc.tris_precomputed)
+        hipLaunchKernelGGL(ptmi_dev::render_kernel<true>, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
+                           first_iteration, n_iterations);
+    else
+        hipLaunchKernelGGL(ptmi_dev::render_kernel<false>, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
+                           first_iteration, n_iterations);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("render_kernel launch: ") + hipGetErrorString(e);

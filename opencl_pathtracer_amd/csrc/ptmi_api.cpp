@@ -7,6 +7,8 @@
 // No CPU fallback exists: without a HIP device nothing here computes.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -53,6 +55,7 @@ struct ptmi_ctx {
     int resident_blocks = 0;
     uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     DScene ds{};
+    DScene* d_scene = nullptr;  // device copy of ds (what the wavefront kernel's path logic reads)
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -84,6 +87,7 @@ void free_scene_memory(ptmi_ctx* ctx)
     ctx->d_hist = nullptr;
     ctx->d_counters = nullptr;
     ctx->d_job_counter = nullptr;
+    ctx->d_scene = nullptr;
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     ctx->d_stage = nullptr;
     ctx->stage_iterations = 0;
@@ -112,6 +116,7 @@ struct Relayout {
     std::vector<DShade> shade;
     std::vector<DMat> mats;
     std::vector<DBigLeaf> big_leaves;
+    bool tris_precomputed = false;
     uint32_t root_ref = 0;
     uint32_t max_depth = 0;
 };
@@ -172,6 +177,34 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         std::memcpy(s.uvn, &t.uvn1, 24);
         s.mat_pos = t.mat_pos;
         s.mat_neg = t.mat_neg;
+    }
+
+    // Ray-independent part of the triangle test, if every triangle keeps the importers' convention of equal w
+    // on its three vertices (then the edge vectors have w = +0 exactly).  Same operations, same order, same
+    // rounding as the kernel's generic form: dot() = fma chain over four components (ptmi_device.hpp).
+    out.tris_precomputed = std::getenv("PTMI_GENERIC_TRIANGLES") == nullptr;  // developer switch for A/B runs
+    for (uint32_t i = 0; i < nt && out.tris_precomputed; i++) {
+        const ptmi_triangle& t = sc->triangulation[i];
+        if (!(t.s1.w == t.s2.w && t.s1.w == t.s3.w)) out.tris_precomputed = false;
+    }
+    if (out.tris_precomputed) {
+        auto dot4 = [](const float a[4], const float b[4]) {
+            return std::fmaf(a[3], b[3], std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])));
+        };
+        for (uint32_t i = 0; i < nt; i++) {
+            const ptmi_triangle& t = sc->triangulation[i];
+            const float S1[4] = {t.s1.x, t.s1.y, t.s1.z, t.s1.w}, N[4] = {t.n.x, t.n.y, t.n.z, t.n.w};
+            const float u[4] = {t.s2.x - t.s1.x, t.s2.y - t.s1.y, t.s2.z - t.s1.z, t.s2.w - t.s1.w};
+            const float v[4] = {t.s3.x - t.s1.x, t.s3.y - t.s1.y, t.s3.z - t.s1.z, t.s3.w - t.s1.w};
+            const float uv = dot4(u, v), uu = dot4(u, u), vv = dot4(v, v);
+            const float denom = 1 / (uv * uv - uu * vv);
+            DTriPre p;
+            std::memcpy(p.n, N, 16);
+            p.s1d[0] = S1[0]; p.s1d[1] = S1[1]; p.s1d[2] = S1[2]; p.s1d[3] = dot4(N, S1);
+            p.u_den[0] = u[0]; p.u_den[1] = u[1]; p.u_den[2] = u[2]; p.u_den[3] = denom;
+            p.v_s1w[0] = v[0]; p.v_s1w[1] = v[1]; p.v_s1w[2] = v[2]; p.v_s1w[3] = S1[3];
+            std::memcpy(&out.tris[i], &p, sizeof p);
+        }
     }
 
     // Walk the tree from bvh[0] exactly as the traversal could, numbering inner
@@ -350,6 +383,9 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     HIP_TRY(ctx, hipMalloc(&dn, npix * 4));  ctx->allocations.push_back(dn);
     HIP_TRY(ctx, hipMalloc(&dh, hist_words * 4)); ctx->allocations.push_back(dh);
     HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8 + 64)); ctx->allocations.push_back(dk);
+    void* dsc = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dsc, sizeof(DScene))); ctx->allocations.push_back(dsc);
+    ctx->d_scene = (DScene*)dsc;
     ctx->d_color = (float*)dc; ctx->d_count = (float*)dn; ctx->d_hist = (uint32_t*)dh;
     ctx->d_counters = (unsigned long long*)dk;
     ctx->d_job_counter = (uint32_t*)((char*)dk + C_COUNT * 8);
@@ -378,6 +414,7 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     // a ray holds at most one pending far child per level it has descended
     ctx->stack_levels = lay.max_depth < 1 ? 1 : lay.max_depth;
     ctx->resident_blocks = wavefront_resident_blocks(ctx->device, ctx->stack_levels);
+    ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
     ds.root_ref = lay.root_ref;
     ds.width = ctx->cfg.image_width;
     ds.height = ctx->cfg.image_height;
@@ -385,6 +422,7 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     ds.n_lights = ctx->cfg.lights_size;
     ds.sampler = ctx->cfg.sampler;
 
+    HIP_TRY(ctx, hipMemcpy(ctx->d_scene, &ctx->ds, sizeof(DScene), hipMemcpyHostToDevice));
     ctx->have_scene = true;
     if (int rc = ptmi_clear(ctx)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
@@ -451,7 +489,7 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
             // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
             const uint32_t cap = ctx->cfg.super_sampling ? 1u : kMaxIterationsPerLaunch;
             const uint32_t n = n_iterations - done < cap ? n_iterations - done : cap;
-            rc = launch_render_wavefront(ctx->ds, first_iteration + done, n, ctx->d_job_counter, ctx->resident_blocks,
+            rc = launch_render_wavefront(ctx->ds, ctx->d_scene, first_iteration + done, n, ctx->d_job_counter, ctx->resident_blocks,
                                          ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0,
                                          ctx->d_stage, ctx->stream, &err);
             done += n;
@@ -555,6 +593,7 @@ int ptmi_bind_accumulators(ptmi_ctx* ctx, void* d_color, void* d_count)
     ctx->ds.image_color = d_color ? (float*)d_color : ctx->d_color;
     ctx->ds.image_ray_nb = d_count ? (float*)d_count : ctx->d_count;
     ctx->accum_bound = d_color != nullptr;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_scene, &ctx->ds, sizeof(DScene), hipMemcpyHostToDevice));
     return PTMI_OK;
 }
 

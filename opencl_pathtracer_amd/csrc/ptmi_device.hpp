@@ -160,6 +160,46 @@ __device__ __forceinline__ bool tri_hit(const V4 S1, const V4 S2, const V4 S3, c
     return true;
 }
 
+// The same test on a DTriPre record: d, the edge vectors and the reciprocal determinant come from the upload.
+// uv, uu, vv are re-evaluated (12 fma) with the w lanes the generic form would see (+0 * +0), and w.w = q.w - S1.w
+// still enters wv / wu multiplied by that +0, so every intermediate equals the generic form's bit for bit.
+__device__ __forceinline__ bool tri_hit_pre(const V4 N, const V4 s1d, const V4 u_den, const V4 v_s1w, const Ray& r,
+                                            float& limit, Hit& h)
+{
+    const V4 S1 = v4(s1d.x, s1d.y, s1d.z, v_s1w.w);
+    const V4 u = v4(u_den.x, u_den.y, u_den.z, 0.0f);
+    const V4 v = v4(v_s1w.x, v_s1w.y, v_s1w.z, 0.0f);
+    const float d = s1d.w;
+    const float nd = dot(N, r.d);
+    if ((nd > -0.00001f) && (nd < 0.00001f)) return false;
+    const V4 q = r.o + (r.d * ((d - dot(N, r.o)) / nd));
+    const V4 full = q - r.o;
+    const float nsd = dot(full, full);
+    if (nsd > limit) return false;
+    if (nsd < 0.00001f) return false;
+    const V4 w = q - S1;
+    const float uv = dot(u, v), wv = dot(w, v), wu = dot(w, u), uu = dot(u, u), vv = dot(v, v);
+    const float denom = u_den.w;
+    const float s = (uv * wv - vv * wu) * denom;
+    const float t = (uv * wu - uu * wv) * denom;
+    if (s < 0 || t < 0 || s + t > 1) return false;
+    if (dot(full, r.d) < 0) return false;
+    limit = nsd;
+    h.point = q;
+    h.s = s;
+    h.t = t;
+    h.front = nd < 0;
+    return true;
+}
+
+template <bool PRE>
+__device__ __forceinline__ bool tri_hit_record(const float4 a, const float4 b, const float4 c, const float4 d,
+                                               const Ray& r, float& limit, Hit& h)
+{
+    if (PRE) return tri_hit_pre(v4(a), v4(b), v4(c), v4(d), r, limit, h);
+    return tri_hit(v4(a), v4(b), v4(c), v4(d), r, limit, h);
+}
+
 __device__ __forceinline__ bool tri_hit(const DTri* __restrict__ tp, const Ray& r, float& limit, Hit& h)
 {
     const float4* q4 = reinterpret_cast<const float4*>(tp);

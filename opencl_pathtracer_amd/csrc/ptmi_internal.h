@@ -52,6 +52,16 @@ struct DTri {
 };
 static_assert(sizeof(DTri) == 64, "DTri");
 
+// Same 64 bytes, ray-independent part of Triangle_Intersects (FullKernel.cl:528-556) done once at upload:
+//   n = N;  s1d = (S1.xyz, d = dot(N,S1));  u_den = ((S2-S1).xyz, 1/(uv*uv-uu*vv));  v_s1w = ((S3-S1).xyz, S1.w)
+// Valid when S1.w == S2.w == S3.w (every importer writes w = 1), so that (S2-S1).w = (S3-S1).w = +0 exactly.
+// The host evaluates these with the same correctly rounded operations the kernel would (fmaf, no contraction),
+// so the test's results are bit-identical to the generic DTri form.
+struct DTriPre {
+    float n[4], s1d[4], u_den[4], v_s1w[4];
+};
+static_assert(sizeof(DTriPre) == sizeof(DTri), "DTriPre");
+
 struct DShade {
     float n1[4], n2[4], n3[4];
     float uvp[6];  // UVP1.xy UVP2.xy UVP3.xy
@@ -108,6 +118,7 @@ struct DScene {
     uint32_t n_lights;   // LIGHTS_SIZE
     uint32_t sampler;
     uint32_t super_sampling;  // -D SUPER_SAMPLING
+    uint32_t tris_precomputed; // tris[] holds DTriPre records
 };
 
 // kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)
@@ -116,9 +127,10 @@ int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterati
 // kernel_wavefront.hip: persistent wavefront state machine (default)
 // stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30)
 int wavefront_resident_blocks(int device, uint32_t stack_levels);
-int launch_render_wavefront(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t* job_counter,
-                            int resident_blocks, uint32_t stack_levels, bool scheduler_stats, float* stage,
-                            void* stream, std::string* err);
+// scene_in_device_memory = a device copy of `sc` (the kernel takes only the hot fields by value)
+int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
+                            uint32_t n_iterations, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
+                            bool scheduler_stats, float* stage, void* stream, std::string* err);
 
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
 constexpr uint32_t kMaxIterationsPerLaunch = 16;

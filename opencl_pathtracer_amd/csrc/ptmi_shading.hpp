@@ -12,11 +12,13 @@ struct Surface {
 
 // What Kernel_Main does between BVH_IntersectRay and the light loop
 // (FullKernel.cl:1254-1274) plus the deferred Triangle_GetColorValueAt (:591-602).
-__device__ __forceinline__ void load_surface(const DScene& sc, const Ray& r, const Hit& hit, Surface& sf)
+template <class SceneT>
+__device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, const Hit& hit, Surface& sf)
 {
-    const V4 N = v4(sc.tris[hit.tri].n);
     const DShade* sh = &sc.shade[hit.tri];
     const float4* s4 = reinterpret_cast<const float4*>(sh);
+    // geometric normal: first float4 of a DTriPre record, last of a DTri record
+    const V4 N = v4(reinterpret_cast<const float4*>(&sc.tris[hit.tri])[sc.tris_precomputed ? 0 : 3]);
     const V4 N1 = v4(s4[0]), N2 = v4(s4[1]), N3 = v4(s4[2]);
     const uint32_t mat_id = hit.front ? sh->mat_pos : sh->mat_neg;
     sf.mat = sc.mats[mat_id];
@@ -92,7 +94,8 @@ __device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const H
 }
 
 // sampler(), FullKernel.cl:1119-1150
-__device__ __forceinline__ void draw_sample(const DScene& sc, uint32_t gx, uint32_t gy, uint32_t iteration, int& seed,
+template <class SceneT>
+__device__ __forceinline__ void draw_sample(const SceneT& sc, uint32_t gx, uint32_t gy, uint32_t iteration, int& seed,
                                             float& sx, float& sy)
 {
     if (sc.sampler == PTMI_SAMPLER_UNIFORM) {
@@ -117,7 +120,8 @@ __device__ __forceinline__ void draw_sample(const DScene& sc, uint32_t gx, uint3
 }
 
 // pixel a sample lands on, FullKernel.cl:1333-1336 (double arithmetic)
-__device__ __forceinline__ uint32_t sample_pixel(const DScene& sc, float sx, float sy)
+template <class SceneT>
+__device__ __forceinline__ uint32_t sample_pixel(const SceneT& sc, float sx, float sy)
 {
     int px = (int)(((double)sx + 0.5) * (int)sc.width);
     int py = (int)(((double)sy + 0.5) * (int)sc.height);
