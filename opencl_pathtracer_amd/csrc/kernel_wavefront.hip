@@ -40,13 +40,16 @@ namespace ptmi_dev {
 
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
-#ifndef PTMI_WF_POST_THRESHOLD
-#define PTMI_WF_POST_THRESHOLD 8
+#ifndef PTMI_WF_WAIT_DEBT
+// lane-trips of waiting a wave tolerates before it spends a trip on path logic.  Measured on MI355X
+// (Msamples/s, 1M triangles / Cornell box, both 1080p): 48: 471 / 1127, 192: 484 / 2002, 512: 479 / 2729,
+// 1024: 463 / 3004; a fixed threshold of 8 lanes: 474 / 743.
+#define PTMI_WF_WAIT_DEBT 512
 #endif
 #ifndef PTMI_WF_MIN_WAVES
 #define PTMI_WF_MIN_WAVES 4
 #endif
-constexpr int kPostThreshold = PTMI_WF_POST_THRESHOLD;  // lanes waiting for path logic before the wave spends a trip on it
+constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
 // rest of DScene (sky: only when a path escapes; histogram / RANDOM-sampler / SUPER_SAMPLING buffers; counters)
@@ -202,6 +205,14 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         }
     };
 
+    // Scheduling of path logic: a fixed lane threshold cannot serve both a 21-node scene (queries of ~10 steps,
+    // all lanes finish together: waiting for a full wave is nearly free and a threshold of 8 runs the long
+    // path-logic code at 12 % utilisation: 743 vs 2897 Msamples/s on the Cornell box) and a million-triangle
+    // scene (ragged queries of ~120 steps: waiting starves the traversal, optimum ~10 lanes).  So the wave keeps
+    // a WAIT DEBT = sum over traversal trips of the number of lanes that sat waiting, and runs path logic when
+    // the debt crosses a bound: bursts of finishers are served together (and leave path logic in lockstep, which
+    // keeps the following traversal trips uniform), stragglers are not waited for.
+    int wait_debt = 0;
     for (;;) {
         const bool pending = !need_path && tri_i < tri_end;
         const bool want_inner = !need_path && !pending && cur != REF_NONE;
@@ -214,7 +225,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         // all three masks are empty), so every trip advances some lane and the wave drains.
         // (Keep the condition inline: hoisting it into bool variables makes hipcc 7.2 structure the loop
         // differently and costs 36 VGPRs = one wave per SIMD; check `make resources` after every edit.)
-        if (n_p >= kPostThreshold || (n_t == 0 && n_i == 0)) {
+        wait_debt += n_p;
+        if ((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0)) {
+            wait_debt = 0;
             // ================================ P: path logic ========================================
             if (STATS) { trips_p++; lanes_p += n_p; }
             if (want_post) {

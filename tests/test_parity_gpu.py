@@ -154,6 +154,29 @@ def test_many_iterations_in_one_call_are_chunked(scene_factory):
     assert np.array_equal(dep, o_dep) and counters == totals
 
 
+def test_full_size_properties_1080p_1m_triangles(scene_factory):
+    """BASELINE config 3 at full size (1920x1080, 1M triangles, depth 10), where the oracle would take minutes:
+    size-independent properties instead -- every pixel sampled exactly spp times, histograms sum to the paths,
+    counter identities, finite non-negative radiance, and spp shards of two contexts add up to one render."""
+    w, h, d, spp = 1920, 1080, 10, 4
+    sc = scene_factory("tris1m", w, h)
+    color, count, (dep, bbx, tri), c = render_scene(sc, w, h, d, spp)
+    assert (count == spp).all() and np.isfinite(color).all() and (color >= 0).all()
+    paths = w * h * spp
+    assert dep.sum() == paths == c["paths"] and bbx.sum() <= paths and tri.sum() <= paths
+    k = np.arange(d + 1, dtype=np.int64)
+    assert (dep.astype(np.int64) * k).sum() == c["surface_hits"] == c["shadow_rays"]  # one light: one shadow ray per hit
+    assert c["surface_hits"] <= c["segments"] <= c["surface_hits"] + paths
+    k5 = np.arange(5000, dtype=np.int64)
+    assert (bbx.astype(np.int64) * k5).sum() <= c["box_tests"] and c["box_tests"] % 2 == 0  # two box tests per node visit
+    assert 1500 < c["box_tests"] / paths < 1900 and 400 < c["triangle_tests"] / paths < 600  # SURVEY probe: 1675 / 490
+    a, an, (ad, _, _), ac = render_scene(sc, w, h, d, 2, first_iteration=0)
+    b, bn, (bd, _, _), bc = render_scene(sc, w, h, d, 2, first_iteration=2)
+    assert np.array_equal(ad + bd, dep) and all(ac[key] + bc[key] == c[key] for key in c)
+    assert np.array_equal(an + bn, count)
+    assert (cases.rms_per_channel(a + b, an + bn, color, count) <= 1e-6).all()
+
+
 def test_clear_and_reinitialize(scene_factory):
     sc = scene_factory("cornell", 64, 48)
     be = Backend().setup_context(64, 48, 4, 1)
