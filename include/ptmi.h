@@ -54,7 +54,8 @@ typedef struct ptmi_config {
     uint32_t ray_max_depth;  /* -D MAX_REFLECTION_NUMBER (globalVars.rayMaxDepth) */
     uint32_t lights_size;    /* -D LIGHTS_SIZE (globalVars.lightsSize) */
     uint32_t sampler;        /* PTMI_SAMPLER_* : -D SAMPLE_JITTERED / _RANDOM / _UNIFORM */
-    uint32_t super_sampling; /* -D SUPER_SAMPLING (globalVars.superSampling) */
+    uint32_t super_sampling; /* -D SUPER_SAMPLING (globalVars.superSampling): adaptive sampling, FullKernel.cl:1152-1172,1219-1222;
+                                JITTERED / UNIFORM samplers only (PTMI_ERR_UNSUPPORTED otherwise) */
     uint32_t flags;          /* PTMI_FLAG_* */
 } ptmi_config;
 
@@ -117,8 +118,11 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* scene);
 /* Replaces the clSetKernelArg(0, imageId) + clEnqueueNDRangeKernel(W x H) pair
  * of OpenCL_RunKernel's loop (OpenCL.cpp:85-89), generalised to a range:
  * renders iterations [first_iteration, first_iteration + n_iterations) for
- * every pixel and adds them into the accumulators.  Asynchronous on the
- * context's stream. */
+ * every pixel and adds them into the accumulators in iteration order (the
+ * float sums equal a launch-per-iteration loop's bit for bit).  Internally
+ * at most 16 iterations per kernel launch (1 with super_sampling, whose stop
+ * criterion reads the accumulators of the previous iteration).  Asynchronous
+ * on the context's stream. */
 int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations);
 
 /* clFinish (OpenCL.cpp:89). */
