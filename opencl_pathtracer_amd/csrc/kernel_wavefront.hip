@@ -94,11 +94,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
 {
     // traversal stacks: [level][lane], one dword per entry, as many levels as the tree is deep (the reference
     // reserves 30, FullKernel.cl:627; the deepest possible chain of pending far children is the tree depth)
-#ifdef PTMI_WF_STATIC_STACK
-    __shared__ uint32_t stack_mem[kWfStack * kWfBlock];
-#else
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_mem[];
-#endif
     __shared__ unsigned long long block_counters[C_COUNT];
 
     const uint32_t tid = threadIdx.x;
@@ -113,21 +109,15 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     };
     // The closest-hit record (point, s, t, triangle, side) changes only when a closer hit is accepted and is read
     // only by path logic: it lives in LDS behind the stack, [field][lane], not in registers of the hot loop.
-#ifdef PTMI_WF_STATIC_STACK
-    __shared__ uint32_t hit_store[8 * kWfBlock];
-    uint32_t* const hit_mem = &hit_store[tid];
-#else
     uint32_t* const hit_mem = &stack_mem[stack_levels * kWfBlock + tid];
-#endif
     const uint32_t tiles_x = (sc.width + 7u) >> 3;
     const bool owns_pixel = sc.sampler != PTMI_SAMPLER_RANDOM;
-    const uint32_t it_end = first_iteration + n_iterations;
     const uint32_t jobs_per_iteration = n_jobs / n_iterations;
 
     // ---- lane state -----------------------------------------------------------------------------
     bool alive = true;       // may still receive work
     bool need_path = true;   // no path in flight
-    uint32_t gx = 0, gy = 0, it = it_end;
+    uint32_t gx = 0, gy = 0, it = first_iteration;
     // path
     int seed = 1;
     float sample_x = 0, sample_y = 0;
@@ -496,10 +486,6 @@ static uint32_t clamp_levels(uint32_t stack_levels)
 
 static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
-#ifdef PTMI_WF_STATIC_STACK
-    (void)stack_levels;
-    return 0;
-#endif
     stack_levels = clamp_levels(stack_levels);
     return (size_t)(stack_levels + 8) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // stack + closest-hit record
 }
