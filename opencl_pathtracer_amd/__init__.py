@@ -5,7 +5,7 @@
 `structs`  - numpy dtypes of the scene contract (include/ptmi_scene.h)
 `scene_cache` - the reference's scene-cache files (sizes.pth / pointers.pth / textureData.pth)
 """
-from . import structs, scenes, backend, scene_cache, output  # noqa: F401
+from . import structs, scenes, backend, scene_cache, output, obj_import  # noqa: F401
 from .backend import Backend, PtmiError, bvh_create, render_scene  # noqa: F401
 
-__all__ = ["structs", "scenes", "backend", "scene_cache", "output", "Backend", "PtmiError", "bvh_create", "render_scene"]
+__all__ = ["structs", "scenes", "backend", "scene_cache", "output", "obj_import", "Backend", "PtmiError", "bvh_create", "render_scene"]
