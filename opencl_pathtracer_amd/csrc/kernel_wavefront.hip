@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 const float4* rec = pending ? reinterpret_cast<const float4*>(&sc.tris[tri_i])
                                             : reinterpret_cast<const float4*>(&sc.nodes[cur & REF_INDEX_MASK_INNER]);
                 const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+                bool need_pop = false;
                 if (pending) {
                     // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
                     Hit h;
@@ -377,10 +378,6 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         }
                     }
                     tri_i++;
-                    if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {  // next pending node is a leaf too
-                        decode_leaf(sc, cur, tri_i, tri_end);
-                        cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
-                    }
                 } else {
                     // ---- one inner-node step (:660-697)
                     const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
@@ -393,13 +390,28 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     p_bbx += 2;
                     const uint32_t near_ref = fwd ? ref1 : ref2, far_ref = fwd ? ref2 : ref1;
                     const bool near_hit = fwd ? h1 : h2, far_hit = fwd ? h2 : h1;
-                    if (near_hit & far_hit) stack[(top++) * kWfBlock] = far_ref;
+                    // push without a branch: lanes that do not push write to the spare level behind the stack
+                    const bool both = near_hit & far_hit;
+                    stack[(both ? top : (int)stack_levels + 8) * kWfBlock] = far_ref;
+                    top += both ? 1 : 0;
                     cur = near_hit ? near_ref : far_ref;
-                    if (!(near_hit | far_hit)) cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
-                    if (cur != REF_NONE && (cur & REF_LEAF)) {  // reached a leaf: its triangles are next
-                        decode_leaf(sc, cur, tri_i, tri_end);
-                        cur = top ? stack[(--top) * kWfBlock] : REF_NONE;
-                    }
+                    need_pop = !(near_hit | far_hit);
+                }
+                // ---- common tail of both step kinds, branch-free pops (an LDS read every lane can afford)
+                {
+                    const int t1 = top > 0 ? top - 1 : 0;
+                    const uint32_t popped = stack[t1 * kWfBlock];
+                    cur = need_pop ? (top > 0 ? popped : REF_NONE) : cur;
+                    top = need_pop ? t1 : top;
+                }
+                // the triangle range is free and the next node is a leaf: its triangles come next, and the node
+                // after them is whatever is pending on the stack  (kept as a branch: the select form measured -1 %)
+                if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {
+                    decode_leaf(sc, cur, tri_i, tri_end);
+                    const int t1 = top > 0 ? top - 1 : 0;
+                    const uint32_t popped = stack[t1 * kWfBlock];
+                    cur = top > 0 ? popped : REF_NONE;
+                    top = t1;
                 }
             }
         }
@@ -487,7 +499,7 @@ static uint32_t clamp_levels(uint32_t stack_levels)
 static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
     stack_levels = clamp_levels(stack_levels);
-    return (size_t)(stack_levels + 8) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // stack + closest-hit record
+    return (size_t)(stack_levels + 9) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // stack + closest-hit record + dump level
 }
 
 int wavefront_resident_blocks(int device, uint32_t stack_levels)
