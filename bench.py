@@ -155,9 +155,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {len(scene.triangulation)} random triangles "
+            "config": {"workload": f"{workload_name(args.scene)}: {len(scene.triangulation)} triangles "
                                    f"({len(scene.bvh)} BVH nodes, depth {scene.bvhMaxDepth}), {W}x{H}, "
-                                   f"ray depth {D}, JITTERED, {scene.lightsSize} point light",
+                                   f"ray depth {D}, JITTERED, {scene.lightsSize} light(s)",
                        "spp_per_step_per_gpu": B, "spp_total": args.steps * B * world,
                        "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU",
                        "scene_build_s": round(t_scene, 2)},
@@ -184,6 +184,12 @@ def main():
     be.release()
     if world > 1:
         dist.destroy_process_group()
+
+
+def workload_name(scene):
+    return {"tris1m": "BASELINE configs[2]: synthetic random-triangle scene (numpy MT19937 seed 12345)",
+            "cornell": "BASELINE configs[1]: Cornell box (point light under a lamp quad)",
+            "matmix": "BASELINE configs[4] stand-in: textured multi-material scene (no Maya assets exist)"}.get(scene, scene)
 
 
 def committed_traffic(args, W, H, D, B):
