@@ -47,7 +47,10 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #define PTMI_WF_WAIT_DEBT 512
 #endif
 #ifndef PTMI_WF_MIN_WAVES
-#define PTMI_WF_MIN_WAVES 4
+// waves per SIMD the register allocator must fit (5 -> 96 VGPRs, the overflow spills to scratch inside the path-logic
+// code, which is ~1 % of the loop trips).  Measured on MI355X, same box (Msamples/s, 1M triangles / Cornell / material
+// mix 4K): 3: 415, 4: 500 / 2731 / 1382, 5: 533 / 2708 / 1375, 6: 409.
+#define PTMI_WF_MIN_WAVES 5
 #endif
 constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Per-launch means of the rocprofv3 --pmc counters of render_wavefront_kernel (input: the directory
+tools/profile_round.sh wrote).  FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; bench.py converts
+them to HBM bytes with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE x 2)."""
+import csv, glob, json, sys
+from collections import defaultdict
+
+acc = defaultdict(lambda: defaultdict(float))
+for f in glob.glob(sys.argv[1] + "/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "render_wavefront_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+out = {}
+for name, per_dispatch in acc.items():
+    v = list(per_dispatch.values())[1:] or list(per_dispatch.values())  # drop the warm-up launch
+    out[name] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
+out["_note"] = ("rocprofv3 --pmc <one group per run> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
+                "--no-cpu-baseline (8 spp per launch, 1M-triangle 1080p workload); FETCH_SIZE/WRITE_SIZE in KB")
+print(json.dumps(out, indent=1))
