@@ -134,12 +134,6 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     bool shadow = false, found = false;
     uint32_t cur = REF_NONE, tri_i = 0, tri_end = 0;
     int top = 0;
-    auto store_hit = [&](const Hit& h) {
-        hit_mem[0 * kWfBlock] = __float_as_uint(h.point.x); hit_mem[1 * kWfBlock] = __float_as_uint(h.point.y);
-        hit_mem[2 * kWfBlock] = __float_as_uint(h.point.z); hit_mem[3 * kWfBlock] = __float_as_uint(h.point.w);
-        hit_mem[4 * kWfBlock] = __float_as_uint(h.s); hit_mem[5 * kWfBlock] = __float_as_uint(h.t);
-        hit_mem[6 * kWfBlock] = h.tri; hit_mem[7 * kWfBlock] = h.front ? 1u : 0u;
-    };
     auto load_hit_point = [&]() {
         return v4(__uint_as_float(hit_mem[0 * kWfBlock]), __uint_as_float(hit_mem[1 * kWfBlock]),
                   __uint_as_float(hit_mem[2 * kWfBlock]), __uint_as_float(hit_mem[3 * kWfBlock]));
@@ -368,18 +362,23 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 bool need_pop = false;
                 if (pending) {
                     // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
-                    Hit h;
                     p_tri++;
-                    if (tri_hit_record<PRE>(a, b, c, d, r, limit, h)) {
-                        found = true;
-                        if (shadow) {  // any hit ends a shadow query (:724-727)
-                            tri_end = tri_i;
-                            cur = REF_NONE; top = 0;
-                        } else {
-                            h.tri = tri_i;
-                            store_hit(h);
+                    bool accepted = false;
+                    tri_test<PRE>(a, b, c, d, r, limit, [&](const V4& q, float s, float t, bool front, float nsd) {
+                        accepted = true;
+                        limit = nsd;
+                        if (!shadow) {  // closest hit so far: the record path logic will shade from
+                            hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
+                            hit_mem[2 * kWfBlock] = __float_as_uint(q.z); hit_mem[3 * kWfBlock] = __float_as_uint(q.w);
+                            hit_mem[4 * kWfBlock] = __float_as_uint(s); hit_mem[5 * kWfBlock] = __float_as_uint(t);
+                            hit_mem[6 * kWfBlock] = tri_i; hit_mem[7 * kWfBlock] = front ? 1u : 0u;
                         }
-                    }
+                    });
+                    found |= accepted;
+                    const bool stop = accepted & shadow;  // any hit ends a shadow query (:724-727)
+                    tri_end = stop ? tri_i : tri_end;
+                    cur = stop ? REF_NONE : cur;
+                    top = stop ? 0 : top;
                     tri_i++;
                 } else {
                     // ---- one inner-node step (:660-697)

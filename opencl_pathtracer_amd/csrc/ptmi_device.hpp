@@ -200,6 +200,47 @@ __device__ __forceinline__ bool tri_hit_record(const float4 a, const float4 b, c
     return tri_hit(v4(a), v4(b), v4(c), v4(d), r, limit, h);
 }
 
+// The same test shaped for the wavefront kernel's instruction budget (it is VALU-issue bound): two nesting levels
+// instead of five, and the accepted hit is consumed by `on_accept(q, s, t, front, nsd)` INSIDE the innermost
+// block, so no value has to be merged back through the early exits (each merge level cost a v_mov per live value).
+// The rejections are the reference's (FullKernel.cl:519-589) with unchanged operands; only their order differs -
+// the behind-the-ray test (:566) moves up next to the distance tests - which cannot change the outcome because the
+// function has no side effects before it accepts.
+template <bool PRE, class OnAccept>
+__device__ __forceinline__ void tri_test(const float4 ra, const float4 rb, const float4 rc, const float4 rd, const Ray& r,
+                                         const float limit, OnAccept&& on_accept)
+{
+    V4 N, S1, u, v;
+    float d;
+    if (PRE) {  // DTriPre: n | s1 + d | u + 1/det | v + S1.w
+        N = v4(ra);
+        S1 = v4(rb.x, rb.y, rb.z, rd.w);
+        u = v4(rc.x, rc.y, rc.z, 0.0f);
+        v = v4(rd.x, rd.y, rd.z, 0.0f);
+        d = rb.w;
+    } else {  // DTri: s1 | s2 | s3 | n
+        S1 = v4(ra);
+        N = v4(rd);
+        u = v4(rb) - S1;
+        v = v4(rc) - S1;
+        d = dot(N, S1);
+    }
+    const float nd = dot(N, r.d);
+    const V4 q = r.o + (r.d * ((d - dot(N, r.o)) / nd));
+    const V4 full = q - r.o;
+    const float nsd = dot(full, full);
+    const float fd = dot(full, r.d);
+    const bool reject = ((nd > -0.00001f) & (nd < 0.00001f)) | (nsd > limit) | (nsd < 0.00001f) | (fd < 0);
+    if (!reject) {
+        const V4 w = q - S1;
+        const float uv = dot(u, v), wv = dot(w, v), wu = dot(w, u), uu = dot(u, u), vv = dot(v, v);
+        const float denom = PRE ? rc.w : 1 / (uv * uv - uu * vv);
+        const float s = (uv * wv - vv * wu) * denom;
+        const float t = (uv * wu - uu * wv) * denom;
+        if (!((s < 0) | (t < 0) | (s + t > 1))) on_accept(q, s, t, nd < 0, nsd);
+    }
+}
+
 __device__ __forceinline__ bool tri_hit(const DTri* __restrict__ tp, const Ray& r, float& limit, Hit& h)
 {
     const float4* q4 = reinterpret_cast<const float4*>(tp);
