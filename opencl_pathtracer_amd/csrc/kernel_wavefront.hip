@@ -72,6 +72,7 @@ struct DWarm {
     uint32_t width, height;
     uint32_t max_depth, n_lights, sampler, tris_precomputed;
     uint32_t histograms;  // hist_depths != nullptr
+    uint32_t boxes_ordered;
 };
 
 __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint32_t& tri_i, uint32_t& tri_end)
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     r.o = v4(0, 0, 0, 0); r.d = v4(0, 0, 0, 0); r.ix = r.iy = r.iz = 0;
     float limit = 0;
     bool shadow = false, found = false;
+    bool exact_boxes = false;  // this ray needs the literal box test (see box_hit_ordered)
     uint32_t cur = REF_NONE, tri_i = 0, tri_end = 0;
     int top = 0;
     auto load_hit_point = [&]() {
@@ -186,6 +188,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     auto start_query = [&]() {
         cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
         found = false;
+        exact_boxes = !(sc.boxes_ordered && ray_slabs_are_ordered(r));
         if (cur & REF_LEAF) {  // the whole scene is one leaf
             decode_leaf(sc, cur, tri_i, tri_end);
             cur = REF_NONE;
@@ -387,8 +390,14 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
                     const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
                     const bool fwd = da > 0;
-                    const bool h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
-                    const bool h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                    bool h1, h2;
+                    if (__builtin_amdgcn_ballot_w64(exact_boxes) == 0ull) {  // wave-uniform: nearly always
+                        h1 = box_hit_ordered(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
+                        h2 = box_hit_ordered(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                    } else {
+                        h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
+                        h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                    }
                     p_bbx += 2;
                     const uint32_t near_ref = fwd ? ref1 : ref2, far_ref = fwd ? ref2 : ref1;
                     const bool near_hit = fwd ? h1 : h2, far_hit = fwd ? h2 : h1;
@@ -542,6 +551,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         warm.root_ref = sc.root_ref; warm.width = sc.width; warm.height = sc.height; warm.max_depth = sc.max_depth;
         warm.n_lights = sc.n_lights; warm.sampler = sc.sampler; warm.tris_precomputed = sc.tris_precomputed;
         warm.histograms = sc.hist_depths != nullptr;
+        warm.boxes_ordered = sc.boxes_ordered;
 #define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
     hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
                        first_iteration, n_iterations, n_jobs, job_counter, lv, stage)

@@ -117,6 +117,7 @@ struct Relayout {
     std::vector<DMat> mats;
     std::vector<DBigLeaf> big_leaves;
     bool tris_precomputed = false;
+    bool boxes_ordered = true;  // all non-empty child boxes finite with pMin <= pMax
     uint32_t root_ref = 0;
     uint32_t max_depth = 0;
 };
@@ -255,6 +256,11 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         d.lo2[0] = b2.p_min.x; d.lo2[1] = b2.p_min.y; d.lo2[2] = b2.p_min.z;
         d.hi2[0] = b2.p_max.x; d.hi2[1] = b2.p_max.y; d.hi2[2] = b2.p_max.z;
         d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.pad = 0;
+        // the short slab test (box_hit_ordered) needs finite, ordered boxes; anything else keeps the literal form
+        for (int k = 0; k < 3; k++) {
+            if (!(r1 & REF_EMPTY) && !(std::isfinite(d.lo1[k]) && std::isfinite(d.hi1[k]) && d.lo1[k] <= d.hi1[k])) out.boxes_ordered = false;
+            if (!(r2 & REF_EMPTY) && !(std::isfinite(d.lo2[k]) && std::isfinite(d.hi2[k]) && d.lo2[k] <= d.hi2[k])) out.boxes_ordered = false;
+        }
         const uint32_t child_depth = it.depth + 1;
         if (child_depth > out.max_depth) out.max_depth = child_depth;
         // push son2 first so son1's subtree is numbered right after its parent
@@ -415,6 +421,7 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     ctx->stack_levels = lay.max_depth < 1 ? 1 : lay.max_depth;
     ctx->resident_blocks = wavefront_resident_blocks(ctx->device, ctx->stack_levels);
     ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
+    ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
     ds.root_ref = lay.root_ref;
     ds.width = ctx->cfg.image_width;
     ds.height = ctx->cfg.image_height;

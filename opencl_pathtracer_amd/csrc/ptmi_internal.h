@@ -119,6 +119,7 @@ struct DScene {
     uint32_t sampler;
     uint32_t super_sampling;  // -D SUPER_SAMPLING
     uint32_t tris_precomputed; // tris[] holds DTriPre records
+    uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)
 };
 
 // kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)

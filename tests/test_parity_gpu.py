@@ -145,6 +145,37 @@ def test_unconventional_w_components(kernel, scene_factory):
     assert (same | nan_both).all()
 
 
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_axis_aligned_rays_and_unordered_boxes_take_the_literal_box_test(kernel, scene_factory):
+    """The wavefront kernel's short slab test (box_hit_ordered) is only valid without NaNs; rays with a zero
+    direction component (reciprocal +-inf, and the reference's quirk that a +0 component fails every box while -0
+    works, FullKernel.cl:79-83) and trees whose boxes are not pMin <= pMax must take the literal form."""
+    import copy
+    from opencl_pathtracer_amd import scenes
+    base = scene_factory("cornell", 64, 48)
+    for direction in ((0.0, 0.0, -1.0), (-0.0, -0.0, -1.0), (0.0, 1.0, 0.0)):
+        sc = copy.copy(base)
+        sc.lights = scenes._records([scenes.light_directional(direction, power=2.0),
+                                     scenes.light_point((278.0, 279.5, 420.0), power=60000.0)], S.Light)
+        # shadow rays start on axis-aligned walls: many box planes pass exactly through the origin (0 * inf)
+        color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 3, sampler=S.UNIFORM, flags=KERNELS[kernel])
+        o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 64, 48, 4, 3, sampler=S.UNIFORM)
+        assert counters == totals, direction
+        assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+    # a hand-made tree with one inverted box: every ray must fall back to the literal test
+    sc = copy.copy(scene_factory("tris20k", 96, 64))
+    bvh = sc.bvh.copy()
+    inner = np.flatnonzero(bvh["isLeaf"] == 0)[5]
+    lo, hi = bvh["trianglesAABB"]["pMin"][inner].copy(), bvh["trianglesAABB"]["pMax"][inner].copy()
+    bvh["trianglesAABB"]["pMin"][inner, 0], bvh["trianglesAABB"]["pMax"][inner, 0] = hi[0], lo[0]
+    sc.bvh = bvh
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 96, 64, 6, 2, flags=KERNELS[kernel])
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 96, 64, 6, 2)
+    assert counters == totals and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+
+
 def test_many_iterations_in_one_call_are_chunked(scene_factory):
     """ptmi_render splits a long range into launches of <= 16 iterations (staging array bound): same bits."""
     sc = scene_factory("cornell", 64, 48)
