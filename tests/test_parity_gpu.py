@@ -163,6 +163,26 @@ def test_axis_aligned_rays_and_unordered_boxes_take_the_literal_box_test(kernel,
         assert counters == totals, direction
         assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
         assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+    # 0 * inf: all camera rays lie in the plane x = 278 (d.x = -0 for a quarter of them, +0 for the rest) and 300
+    # small triangles put box planes exactly there, so slab ends are NaN and only the literal comparisons decide
+    # (checked once by mutation: with the per-ray check disabled this case fails)
+    rs = np.random.RandomState(3)
+    c = rs.uniform((150, 50, 50), (400, 500, 500), (300, 3)).astype(np.float32)
+    v = (c[:, None, :] + rs.uniform(-40, 40, (300, 3, 3))).astype(np.float32)
+    side = rs.randint(0, 2, 300)
+    v[:, 0, 0] = 278.0  # first vertex on the plane, the others strictly on one side of it
+    v[:, 1:, 0] = np.where(side[:, None] == 1, 278.0 + rs.uniform(1, 60, (300, 2)), 278.0 - rs.uniform(1, 60, (300, 2)))
+    extra = scenes.triangle_create(v[:, 0], v[:, 1], v[:, 2])
+    sc = _custom_scene(scenes._concat_tris([base.triangulation.copy(), extra]), base)
+    sc.cameraPosition = np.array([278.0, -800.0, 273.0, 1.0], np.float32)
+    sc.cameraDirection = np.array([-0.0, 1.0, 0.0, 0.0], np.float32)
+    sc.cameraRight = np.array([0.0, 0.0, 0.5, 0.0], np.float32)
+    sc.cameraUp = np.array([0.0, 0.0, 0.3, 0.0], np.float32)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 3, flags=KERNELS[kernel])
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 64, 48, 4, 3)
+    assert counters == totals and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+    assert counters["surface_hits"] > 0
     # a hand-made tree with one inverted box: every ray must fall back to the literal test
     sc = copy.copy(scene_factory("tris20k", 96, 64))
     bvh = sc.bvh.copy()
