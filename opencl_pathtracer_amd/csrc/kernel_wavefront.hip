@@ -104,7 +104,13 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     const uint32_t tid = threadIdx.x;
     if (tid < C_COUNT) block_counters[tid] = 0;
     __syncthreads();
-    uint32_t* const stack = &stack_mem[tid];
+    // LDS: [closest-hit record: 8][sentinel][stack levels...], each level one dword per lane.  The sentinel below the
+    // stack holds REF_NONE: popping an empty stack yields "query finished" without a test (and, sitting behind the
+    // hit record, its address minus one level cannot wrap below zero).  Pushes write the slot above the top for
+    // every lane and move the top only for pushing lanes; an inner node at depth k has at most k pending entries
+    // above it, so that slot is always inside the `stack_levels` = tree depth levels.
+    uint32_t* const stack_floor = &stack_mem[8 * kWfBlock + tid];
+    *stack_floor = REF_NONE;
     // the rare fields: pointer re-derived through an opaque asm so the loads stay where they are used
     auto cold_scene = [&]() -> const DScene& {
         const DScene* p = scene_in_memory;
@@ -112,8 +118,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         return *p;
     };
     // The closest-hit record (point, s, t, triangle, side) changes only when a closer hit is accepted and is read
-    // only by path logic: it lives in LDS behind the stack, [field][lane], not in registers of the hot loop.
-    uint32_t* const hit_mem = &stack_mem[stack_levels * kWfBlock + tid];
+    // only by path logic: it lives in LDS in front of the stack, [field][lane], not in registers of the hot loop.
+    uint32_t* const hit_mem = &stack_mem[tid];
     const uint32_t tiles_x = (sc.width + 7u) >> 3;
     const bool owns_pixel = sc.sampler != PTMI_SAMPLER_RANDOM;
     const uint32_t jobs_per_iteration = n_jobs / n_iterations;
@@ -135,7 +141,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     bool shadow = false, found = false;
     bool exact_boxes = false;  // this ray needs the literal box test (see box_hit_ordered)
     uint32_t cur = REF_NONE, tri_i = 0, tri_end = 0;
-    int top = 0;
+    uint32_t* sp = stack_floor;  // the top entry (the sentinel when the stack is empty)
     auto load_hit_point = [&]() {
         return v4(__uint_as_float(hit_mem[0 * kWfBlock]), __uint_as_float(hit_mem[1 * kWfBlock]),
                   __uint_as_float(hit_mem[2 * kWfBlock]), __uint_as_float(hit_mem[3 * kWfBlock]));
@@ -186,7 +192,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // is an inner-node reference or REF_NONE; a leaf reference is decoded into [tri_i, tri_end) as soon as
     // the range is free.
     auto start_query = [&]() {
-        cur = sc.root_ref; top = 0; tri_i = tri_end = 0;
+        cur = sc.root_ref; sp = stack_floor; tri_i = tri_end = 0;
         found = false;
         exact_boxes = !(sc.boxes_ordered && ray_slabs_are_ordered(r));
         if (cur & REF_LEAF) {  // the whole scene is one leaf
@@ -207,7 +213,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         const bool pending = !need_path && tri_i < tri_end;
         const bool want_inner = !need_path && !pending && cur != REF_NONE;
         const bool want_post = alive && (need_path || (!pending && cur == REF_NONE));
-        const unsigned long long m_t = __ballot(pending), m_i = __ballot(want_inner), m_p = __ballot(want_post);
+        const unsigned long long m_t = __builtin_amdgcn_ballot_w64(pending), m_i = __builtin_amdgcn_ballot_w64(want_inner),
+                                 m_p = __builtin_amdgcn_ballot_w64(want_post);
         if ((m_t | m_i | m_p) == 0ull) break;
         const int n_t = __popcll(m_t), n_i = __popcll(m_i), n_p = __popcll(m_p);
 
@@ -381,7 +388,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     const bool stop = accepted & shadow;  // any hit ends a shadow query (:724-727)
                     tri_end = stop ? tri_i : tri_end;
                     cur = stop ? REF_NONE : cur;
-                    top = stop ? 0 : top;
+                    sp = stop ? stack_floor : sp;
                     tri_i++;
                 } else {
                     // ---- one inner-node step (:660-697)
@@ -399,30 +406,31 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
                     }
                     p_bbx += 2;
-                    const uint32_t near_ref = fwd ? ref1 : ref2, far_ref = fwd ? ref2 : ref1;
-                    const bool near_hit = fwd ? h1 : h2, far_hit = fwd ? h2 : h1;
-                    // push without a branch: lanes that do not push write to the spare level behind the stack
-                    const bool both = near_hit & far_hit;
-                    stack[(both ? top : (int)stack_levels + 8) * kWfBlock] = far_ref;
-                    top += both ? 1 : 0;
-                    cur = near_hit ? near_ref : far_ref;
-                    need_pop = !(near_hit | far_hit);
+                    // near child = fwd ? son1 : son2 (:663-666); descend into the near one if it was hit, else into the
+                    // far one; push the far one when both were hit.  In terms of son1/son2:
+                    const uint32_t far_ref = fwd ? ref2 : ref1;
+                    const bool both = h1 & h2;
+                    const bool take1 = fwd ? h1 : !h2;
+                    // push without a branch (see the LDS layout above)
+                    sp[kWfBlock] = far_ref;
+                    sp += both ? kWfBlock : 0;
+                    cur = take1 ? ref1 : ref2;
+                    need_pop = !(h1 | h2);
                 }
                 // ---- common tail of both step kinds, branch-free pops (an LDS read every lane can afford)
                 {
-                    const int t1 = top > 0 ? top - 1 : 0;
-                    const uint32_t popped = stack[t1 * kWfBlock];
-                    cur = need_pop ? (top > 0 ? popped : REF_NONE) : cur;
-                    top = need_pop ? t1 : top;
+                    const uint32_t popped = *sp;
+                    uint32_t* const below = sp - kWfBlock;
+                    cur = need_pop ? popped : cur;
+                    sp = need_pop ? (below < stack_floor ? stack_floor : below) : sp;
                 }
                 // the triangle range is free and the next node is a leaf: its triangles come next, and the node
                 // after them is whatever is pending on the stack  (kept as a branch: the select form measured -1 %)
                 if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {
                     decode_leaf(sc, cur, tri_i, tri_end);
-                    const int t1 = top > 0 ? top - 1 : 0;
-                    const uint32_t popped = stack[t1 * kWfBlock];
-                    cur = top > 0 ? popped : REF_NONE;
-                    top = t1;
+                    cur = *sp;
+                    uint32_t* const below = sp - kWfBlock;
+                    sp = below < stack_floor ? stack_floor : below;
                 }
             }
         }
@@ -510,7 +518,7 @@ static uint32_t clamp_levels(uint32_t stack_levels)
 static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
     stack_levels = clamp_levels(stack_levels);
-    return (size_t)(stack_levels + 9) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // stack + closest-hit record + dump level
+    return (size_t)(stack_levels + 9) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // closest-hit record + sentinel + stack
 }
 
 int wavefront_resident_blocks(int device, uint32_t stack_levels)
