@@ -52,6 +52,9 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 // mix 4K): 3: 415, 4: 500 / 2731 / 1382, 5: 533 / 2708 / 1375, 6: 409.
 #define PTMI_WF_MIN_WAVES 5
 #endif
+#ifndef PTMI_WF_LINE_MATES
+#define PTMI_WF_LINE_MATES 0
+#endif
 constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
@@ -63,6 +66,7 @@ struct DWarm {
     const DNode* nodes;
     const DTri* tris;
     const DBigLeaf* big_leaves;
+    const uint32_t* tri_ids;
     const DShade* shade;
     const DMat* mats;
     const ptmi_light* lights;
@@ -73,6 +77,7 @@ struct DWarm {
     uint32_t max_depth, n_lights, sampler, tris_precomputed;
     uint32_t histograms;  // hist_depths != nullptr
     uint32_t boxes_ordered;
+    uint32_t wide_records;  // the record array is 4 GB or more: 64-bit addressing
 };
 
 __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint32_t& tri_i, uint32_t& tri_end)
@@ -365,73 +370,102 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 trips_i += n_i ? 1u : 0u; lanes_i += n_i;
                 trips_t += n_t ? 1u : 0u; lanes_t += n_t;
             }
-            if (pending || want_inner) {
-                const float4* rec = pending ? reinterpret_cast<const float4*>(&sc.tris[tri_i])
-                                            : reinterpret_cast<const float4*>(&sc.nodes[cur & REF_INDEX_MASK_INNER]);
-                const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
-                bool need_pop = false;
-                if (pending) {
-                    // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
-                    p_tri++;
-                    bool accepted = false;
-                    tri_test<PRE>(a, b, c, d, r, limit, [&](const V4& q, float s, float t, bool front, float nsd) {
-                        accepted = true;
-                        limit = nsd;
-                        if (!shadow) {  // closest hit so far: the record path logic will shade from
-                            hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
-                            hit_mem[2 * kWfBlock] = __float_as_uint(q.z); hit_mem[3 * kWfBlock] = __float_as_uint(q.w);
-                            hit_mem[4 * kWfBlock] = __float_as_uint(s); hit_mem[5 * kWfBlock] = __float_as_uint(t);
-                            hit_mem[6 * kWfBlock] = tri_i; hit_mem[7 * kWfBlock] = front ? 1u : 0u;
-                        }
-                    });
-                    found |= accepted;
-                    const bool stop = accepted & shadow;  // any hit ends a shadow query (:724-727)
-                    tri_end = stop ? tri_i : tri_end;
-                    cur = stop ? REF_NONE : cur;
-                    sp = stop ? stack_floor : sp;
-                    tri_i++;
-                } else {
-                    // ---- one inner-node step (:660-697)
-                    const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
-                    const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
-                    const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
-                    const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
-                    const bool fwd = da > 0;
-                    bool h1, h2;
-                    if (__builtin_amdgcn_ballot_w64(exact_boxes) == 0ull) {  // wave-uniform: nearly always
-                        h1 = box_hit_ordered(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
-                        h2 = box_hit_ordered(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+            // LINE-MATE SUB-STEPS.  The integrator is bound by the 64 or so L1 misses a CU can have in flight (time =
+            // sum of miss latencies / 64 per CU, tools/microbench/record_fetch.hip), and the L1 is far too small to keep
+            // a line until the lane's next trip.  So a lane whose NEXT record lies in the 128-byte line it has just
+            // fetched - the second triangle of an aligned pair, or son1 stored right behind its (even-numbered) parent -
+            // takes that step at once, while the line is still in the L1; the other lanes sit the sub-step out.
+            bool go = pending || want_inner;
+            bool is_tri = pending;
+            for (;;) {
+                const uint32_t line_key = is_tri ? ((tri_i >> 1) | 0x80000000u) : ((cur & REF_INDEX_MASK_INNER) >> 1);
+                if (go) {
+                    // nodes and triangles live in one array of 64-byte records (nodes == tris): scalar base + 32-bit
+                    // byte offset while the array is below 4 GB (the shift drops a node reference's flag bits)
+                    float4 a, b, c, d;
+                    if (!sc.wide_records) {
+                        const uint32_t off = (is_tri ? tri_i : cur) << 6;
+                        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + off);
+                        a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3];
                     } else {
-                        h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
-                        h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                        const float4* rec = reinterpret_cast<const float4*>(&sc.tris[is_tri ? tri_i : (cur & REF_INDEX_MASK_INNER)]);
+                        a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3];
                     }
-                    p_bbx += 2;
-                    // near child = fwd ? son1 : son2 (:663-666); descend into the near one if it was hit, else into the
-                    // far one; push the far one when both were hit.  In terms of son1/son2:
-                    const uint32_t far_ref = fwd ? ref2 : ref1;
-                    const bool both = h1 & h2;
-                    const bool take1 = fwd ? h1 : !h2;
-                    // push without a branch (see the LDS layout above)
-                    sp[kWfBlock] = far_ref;
-                    sp += both ? kWfBlock : 0;
-                    cur = take1 ? ref1 : ref2;
-                    need_pop = !(h1 | h2);
+                    bool need_pop = false;
+                    if (is_tri) {
+                        // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
+                        p_tri++;
+                        bool accepted = false;
+                        tri_test<PRE>(a, b, c, d, r, limit, [&](const V4& q, float s, float t, bool front, float nsd) {
+                            accepted = true;
+                            limit = nsd;
+                            if (!shadow) {  // closest hit so far: the record path logic will shade from
+                                hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
+                                hit_mem[2 * kWfBlock] = __float_as_uint(q.z); hit_mem[3 * kWfBlock] = __float_as_uint(q.w);
+                                hit_mem[4 * kWfBlock] = __float_as_uint(s); hit_mem[5 * kWfBlock] = __float_as_uint(t);
+                                hit_mem[6 * kWfBlock] = tri_i; hit_mem[7 * kWfBlock] = front ? 1u : 0u;
+                            }
+                        });
+                        found |= accepted;
+                        const bool stop = accepted & shadow;  // any hit ends a shadow query (:724-727)
+                        tri_end = stop ? tri_i : tri_end;
+                        cur = stop ? REF_NONE : cur;
+                        sp = stop ? stack_floor : sp;
+                        tri_i++;
+                    } else {
+                        // ---- one inner-node step (:660-697)
+                        const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
+                        const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
+                        const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
+                        const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
+                        const bool fwd = da > 0;
+                        bool h1, h2;
+                        if (__builtin_amdgcn_ballot_w64(exact_boxes) == 0ull) {  // wave-uniform: nearly always
+                            h1 = box_hit_ordered(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
+                            h2 = box_hit_ordered(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                        } else {
+                            h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
+                            h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                        }
+                        p_bbx += 2;
+                        // near child = fwd ? son1 : son2 (:663-666); descend into the near one if it was hit, else into the
+                        // far one; push the far one when both were hit.  In terms of son1/son2:
+                        const uint32_t far_ref = fwd ? ref2 : ref1;
+                        const bool both = h1 & h2;
+                        const bool take1 = fwd ? h1 : !h2;
+                        // push without a branch (see the LDS layout above)
+                        sp[kWfBlock] = far_ref;
+                        sp += both ? kWfBlock : 0;
+                        cur = take1 ? ref1 : ref2;
+                        need_pop = !(h1 | h2);
+                    }
+                    // ---- common tail of both step kinds, branch-free pops (an LDS read every lane can afford)
+                    {
+                        const uint32_t popped = *sp;
+                        uint32_t* const below = sp - kWfBlock;
+                        cur = need_pop ? popped : cur;
+                        sp = need_pop ? (below < stack_floor ? stack_floor : below) : sp;
+                    }
+                    // the triangle range is free and the next node is a leaf: its triangles come next, and the node
+                    // after them is whatever is pending on the stack  (kept as a branch: the select form measured -1 %)
+                    if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {
+                        decode_leaf(sc, cur, tri_i, tri_end);
+                        cur = *sp;
+                        uint32_t* const below = sp - kWfBlock;
+                        sp = below < stack_floor ? stack_floor : below;
+                    }
                 }
-                // ---- common tail of both step kinds, branch-free pops (an LDS read every lane can afford)
-                {
-                    const uint32_t popped = *sp;
-                    uint32_t* const below = sp - kWfBlock;
-                    cur = need_pop ? popped : cur;
-                    sp = need_pop ? (below < stack_floor ? stack_floor : below) : sp;
-                }
-                // the triangle range is free and the next node is a leaf: its triangles come next, and the node
-                // after them is whatever is pending on the stack  (kept as a branch: the select form measured -1 %)
-                if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {
-                    decode_leaf(sc, cur, tri_i, tri_end);
-                    cur = *sp;
-                    uint32_t* const below = sp - kWfBlock;
-                    sp = below < stack_floor ? stack_floor : below;
-                }
+#if PTMI_WF_LINE_MATES
+                const bool next_tri = tri_i < tri_end;
+                const bool next_inner = !next_tri && cur != REF_NONE;
+                const uint32_t next_key = next_tri ? ((tri_i >> 1) | 0x80000000u) : ((cur & REF_INDEX_MASK_INNER) >> 1);
+                go = go & (next_tri | next_inner) & (next_key == line_key);
+                if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
+                is_tri = next_tri;
+#else
+                (void)line_key;
+                break;
+#endif
             }
         }
     }
@@ -554,12 +588,13 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         const uint32_t lv = clamp_levels(stack_levels);
         hipStream_t st = (hipStream_t)stream;
         ptmi_dev::DWarm warm{};
-        warm.nodes = sc.nodes; warm.tris = sc.tris; warm.big_leaves = sc.big_leaves; warm.shade = sc.shade;
+        warm.nodes = sc.nodes; warm.tris = sc.tris; warm.big_leaves = sc.big_leaves; warm.tri_ids = sc.tri_ids; warm.shade = sc.shade;
         warm.mats = sc.mats; warm.lights = sc.lights; warm.textures = sc.textures; warm.texels = sc.texels;
         warm.root_ref = sc.root_ref; warm.width = sc.width; warm.height = sc.height; warm.max_depth = sc.max_depth;
         warm.n_lights = sc.n_lights; warm.sampler = sc.sampler; warm.tris_precomputed = sc.tris_precomputed;
         warm.histograms = sc.hist_depths != nullptr;
         warm.boxes_ordered = sc.boxes_ordered;
+        warm.wide_records = sc.wide_records;
 #define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
     hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
                        first_iteration, n_iterations, n_jobs, job_counter, lv, stage)

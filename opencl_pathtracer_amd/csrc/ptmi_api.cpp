@@ -111,8 +111,9 @@ int upload(ptmi_ctx* ctx, const std::vector<T>& host, const T** out)
 // Scene validation + re-layout.  Everything the kernel will index is checked
 // here so that a malformed scene is an error code, not a GPU fault.
 struct Relayout {
-    std::vector<DNode> nodes;
-    std::vector<DTri> tris;
+    std::vector<DTri> recs;          // the traversal's one array: DNode and DTri/DTriPre records interleaved
+    std::vector<uint32_t> tri_ids;   // per record: index into triangulation[] / shade[] (0xFFFFFFFF for a node)
+    std::vector<DTri> tris;          // per input triangle, only a staging area for recs
     std::vector<DShade> shade;
     std::vector<DMat> mats;
     std::vector<DBigLeaf> big_leaves;
@@ -208,54 +209,79 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         }
     }
 
-    // Walk the tree from bvh[0] exactly as the traversal could, numbering inner
-    // nodes in pre-order.  `seen` rejects cycles and shared subtrees.
+    // Walk the tree from bvh[0] exactly as the traversal could and emit ONE array of 64-byte records in depth-first
+    // order: an inner node's record, then the triangles of its leaf children, then son1's subtree, then son2's.
+    // What a ray reads next is then usually the neighbour of what it has just read: the caches fetch 128-byte lines,
+    // so a bottom-level node brings its first triangle along and an even-numbered node its first inner child
+    // (the integrator is bound by cache misses in flight).  `seen` rejects cycles and shared subtrees.
     std::vector<uint8_t> seen(nn, 0);
-    auto make_ref = [&](uint32_t id, uint32_t* ref, std::string* why) -> bool {
-        if (id >= nn) { *why = "child index out of range"; return false; }
-        if (seen[id]) { *why = "node " + std::to_string(id) + " reached twice (cycle or shared subtree)"; return false; }
+    std::string why;
+    auto check_node = [&](uint32_t id) -> bool {
+        if (id >= nn) { why = "child index out of range"; return false; }
+        if (seen[id]) { why = "node " + std::to_string(id) + " reached twice (cycle or shared subtree)"; return false; }
         seen[id] = 1;
         const ptmi_node& n = sc->bvh[id];
-        uint32_t r = n.triangles_aabb.is_empty ? REF_EMPTY : 0u;
         if (n.is_leaf) {
-            if ((uint64_t)n.triangle_start_index + n.nb_triangles > nt) { *why = "leaf triangle range out of bounds"; return false; }
-            r |= REF_LEAF;
-            if (n.nb_triangles < REF_COUNT_BIG) {
-                r |= (n.nb_triangles << REF_COUNT_SHIFT) | n.triangle_start_index;
-            } else {
-                r |= (REF_COUNT_BIG << REF_COUNT_SHIFT) | (uint32_t)out.big_leaves.size();
-                out.big_leaves.push_back(DBigLeaf{n.triangle_start_index, n.nb_triangles});
-            }
+            if ((uint64_t)n.triangle_start_index + n.nb_triangles > nt) { why = "leaf triangle range out of bounds"; return false; }
+        } else if (n.cut_axis > 2) { why = "cutAxis > 2"; return false; }
+        return true;
+    };
+    // appends the triangles of leaf `id` and returns the reference to them
+    auto emit_leaf = [&](uint32_t id, uint32_t* ref) -> bool {
+        const ptmi_node& n = sc->bvh[id];
+        const size_t start = out.recs.size();
+        if (start + n.nb_triangles > REF_INDEX_MASK_LEAF) { why = "more than 2^27 records"; return false; }
+        for (uint32_t k = 0; k < n.nb_triangles; k++) {
+            out.recs.push_back(out.tris[n.triangle_start_index + k]);
+            out.tri_ids.push_back(n.triangle_start_index + k);
+        }
+        uint32_t r = (n.triangles_aabb.is_empty ? REF_EMPTY : 0u) | REF_LEAF;
+        if (n.nb_triangles < REF_COUNT_BIG) {
+            r |= (n.nb_triangles << REF_COUNT_SHIFT) | (uint32_t)start;
         } else {
-            if (n.cut_axis > 2) { *why = "cutAxis > 2"; return false; }
-            r |= (uint32_t)out.nodes.size();
-            out.nodes.emplace_back();
+            r |= (REF_COUNT_BIG << REF_COUNT_SHIFT) | (uint32_t)out.big_leaves.size();
+            out.big_leaves.push_back(DBigLeaf{(uint32_t)start, n.nb_triangles});
         }
         *ref = r;
         return true;
     };
+    auto node_at = [&](size_t rec) -> DNode& { return *reinterpret_cast<DNode*>(&out.recs[rec]); };
 
-    std::string why;
-    if (!make_ref(0, &out.root_ref, &why)) return fail(ctx, PTMI_ERR_BAD_SCENE, "bvh[0]: " + why);
-    struct Item { uint32_t id, dnode, depth; };
+    constexpr uint32_t NO_PARENT = 0xFFFFFFFFu;
+    struct Item { uint32_t id, parent_rec, slot, depth; };
     std::vector<Item> todo;
-    if (!(out.root_ref & REF_LEAF)) todo.push_back({0, out.root_ref & REF_INDEX_MASK_INNER, 0});
+    if (!check_node(0)) return fail(ctx, PTMI_ERR_BAD_SCENE, "bvh[0]: " + why);
+    if (sc->bvh[0].is_leaf) {
+        if (!emit_leaf(0, &out.root_ref)) return fail(ctx, PTMI_ERR_LIMIT, "bvh[0]: " + why);
+    } else {
+        out.root_ref = (sc->bvh[0].triangles_aabb.is_empty ? REF_EMPTY : 0u);  // index 0, patched like any inner child
+        todo.push_back({0, NO_PARENT, 0, 0});
+    }
     while (!todo.empty()) {
         const Item it = todo.back();
         todo.pop_back();
         const ptmi_node& n = sc->bvh[it.id];
-        uint32_t r1, r2;
-        if (!make_ref(n.son1_id, &r1, &why) || !make_ref(n.son2_id, &r2, &why))
+        const size_t self = out.recs.size();
+        if (self > REF_INDEX_MASK_LEAF) return fail(ctx, PTMI_ERR_LIMIT, "more than 2^27 records");
+        out.recs.emplace_back();
+        out.tri_ids.push_back(0xFFFFFFFFu);
+        if (it.parent_rec == NO_PARENT) out.root_ref |= (uint32_t)self;
+        else (it.slot == 0 ? node_at(it.parent_rec).ref1 : node_at(it.parent_rec).ref2) |= (uint32_t)self;
+        if (!check_node(n.son1_id) || !check_node(n.son2_id))
             return fail(ctx, PTMI_ERR_BAD_SCENE, "bvh[" + std::to_string(it.id) + "]: " + why);
-        if (out.nodes.size() > REF_INDEX_MASK_INNER) return fail(ctx, PTMI_ERR_LIMIT, "too many bvh nodes");
-        DNode& d = out.nodes[it.dnode];
-        const ptmi_bounding_box& b1 = sc->bvh[n.son1_id].triangles_aabb;
-        const ptmi_bounding_box& b2 = sc->bvh[n.son2_id].triangles_aabb;
+        const ptmi_node& c1 = sc->bvh[n.son1_id];
+        const ptmi_node& c2 = sc->bvh[n.son2_id];
+        uint32_t r1 = c1.triangles_aabb.is_empty ? REF_EMPTY : 0u, r2 = c2.triangles_aabb.is_empty ? REF_EMPTY : 0u;
+        if (c1.is_leaf && !emit_leaf(n.son1_id, &r1)) return fail(ctx, PTMI_ERR_LIMIT, "bvh[" + std::to_string(it.id) + "]: " + why);
+        if (c2.is_leaf && !emit_leaf(n.son2_id, &r2)) return fail(ctx, PTMI_ERR_LIMIT, "bvh[" + std::to_string(it.id) + "]: " + why);
+        DNode& d = node_at(self);
+        const ptmi_bounding_box& b1 = c1.triangles_aabb;
+        const ptmi_bounding_box& b2 = c2.triangles_aabb;
         d.lo1[0] = b1.p_min.x; d.lo1[1] = b1.p_min.y; d.lo1[2] = b1.p_min.z;
         d.hi1[0] = b1.p_max.x; d.hi1[1] = b1.p_max.y; d.hi1[2] = b1.p_max.z;
         d.lo2[0] = b2.p_min.x; d.lo2[1] = b2.p_min.y; d.lo2[2] = b2.p_min.z;
         d.hi2[0] = b2.p_max.x; d.hi2[1] = b2.p_max.y; d.hi2[2] = b2.p_max.z;
-        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.pad = 0;
+        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.pad = 0;  // inner children: index patched in when they are emitted
         // the short slab test (box_hit_ordered) needs finite, ordered boxes; anything else keeps the literal form
         for (int k = 0; k < 3; k++) {
             if (!(r1 & REF_EMPTY) && !(std::isfinite(d.lo1[k]) && std::isfinite(d.hi1[k]) && d.lo1[k] <= d.hi1[k])) out.boxes_ordered = false;
@@ -263,10 +289,11 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         }
         const uint32_t child_depth = it.depth + 1;
         if (child_depth > out.max_depth) out.max_depth = child_depth;
-        // push son2 first so son1's subtree is numbered right after its parent
-        if (!(r2 & REF_LEAF)) todo.push_back({n.son2_id, r2 & REF_INDEX_MASK_INNER, child_depth});
-        if (!(r1 & REF_LEAF)) todo.push_back({n.son1_id, r1 & REF_INDEX_MASK_INNER, child_depth});
+        // push son2 first so that son1's subtree follows this node's own records
+        if (!c2.is_leaf) todo.push_back({n.son2_id, (uint32_t)self, 1, child_depth});
+        if (!c1.is_leaf) todo.push_back({n.son1_id, (uint32_t)self, 0, child_depth});
     }
+    if (out.recs.empty()) { out.recs.emplace_back(); out.tri_ids.push_back(0xFFFFFFFFu); }  // a root leaf without triangles
     // the traversal stack has 30 entries (FullKernel.cl:627); the reference refuses deeper trees (PathTracer.cpp:54-58)
     if (out.max_depth >= PTMI_BVH_MAX_DEPTH)
         return fail(ctx, PTMI_ERR_LIMIT, "bvh depth " + std::to_string(out.max_depth) + " >= 30");
@@ -368,8 +395,11 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
 
     DScene& ds = ctx->ds;
     ds = DScene{};
-    if (int rc = upload(ctx, lay.nodes, &ds.nodes)) return rc;
-    if (int rc = upload(ctx, lay.tris, &ds.tris)) return rc;
+    if (int rc = upload(ctx, lay.recs, &ds.tris)) return rc;
+    ds.nodes = reinterpret_cast<const DNode*>(ds.tris);  // same array: a reference is an index of 64-byte records
+    ds.n_records = (uint32_t)lay.recs.size();
+    ds.wide_records = (lay.recs.size() > (1u << 26) || std::getenv("PTMI_WIDE_RECORDS") != nullptr) ? 1u : 0u;  // env: test switch
+    if (int rc = upload(ctx, lay.tri_ids, &ds.tri_ids)) return rc;
     if (int rc = upload(ctx, lay.shade, &ds.shade)) return rc;
     if (int rc = upload(ctx, lay.mats, &ds.mats)) return rc;
     if (int rc = upload(ctx, lay.big_leaves, &ds.big_leaves)) return rc;

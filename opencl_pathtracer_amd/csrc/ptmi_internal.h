@@ -19,17 +19,21 @@ void set_global_error(const std::string& msg);
 // record and nothing it does not need:
 //
 //  DNode (64 B, one per INNER node): both children's boxes + child references.
-//  DTri  (64 B, one per triangle, BVH order): S1,S2,S3,N as stored (xyzw).
-//  DShade (112 B, one per triangle): what only a confirmed surface hit reads.
+//  DTri / DTriPre (64 B, one per triangle of a leaf): what the intersection test reads.
+//  DShade (112 B, one per input triangle): what only a confirmed surface hit reads.
 //  DMat  (32 B): material without the host pointer.
+//
+// DNode and DTri records share ONE array in depth-first order (a node, the triangles of its leaf children, son1's
+// subtree, son2's subtree), so DScene::nodes == DScene::tris and every index below is an index of 64-byte records;
+// tri_ids[] maps a triangle record back to its input triangle.
 //
 // A child reference ("ref") packs what the traversal needs to know about the
 // child without touching it:
 //   bit 31      : child is a leaf
 //   bit 30      : child's trianglesAABB.isEmpty (box test returns false, FullKernel.cl:68)
-//   inner child : bits 29..0 = index into DNode[]
+//   inner child : bits 29..0 = record index of its DNode (< 2^27)
 //   leaf child  : bits 29..27 = triangle count 0..6, or 7 = "big leaf";
-//                 bits 26..0  = first triangle (count<=6) or index into big_leaves[]
+//                 bits 26..0  = record index of its first triangle (count<=6) or index into big_leaves[]
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t REF_EMPTY = 0x40000000u;
 constexpr uint32_t REF_COUNT_SHIFT = 27;
@@ -101,6 +105,7 @@ struct DScene {
     const ptmi_texture* textures;
     const ptmi_uchar4* texels;
     const DBigLeaf* big_leaves;
+    const uint32_t* tri_ids;  // record index -> triangle index (shade[], triangulation[])
     float* image_color;   // float4[W*H]
     float* image_ray_nb;  // float[W*H]
     uint32_t* hist_depths;  // [D+1]   (nullptr = histograms off)
@@ -119,6 +124,8 @@ struct DScene {
     uint32_t sampler;
     uint32_t super_sampling;  // -D SUPER_SAMPLING
     uint32_t tris_precomputed; // tris[] holds DTriPre records
+    uint32_t n_records;        // nodes + leaf triangles in the one record array (nodes == tris)
+    uint32_t wide_records;     // that array is 4 GB or more: byte offsets need 64 bits
     uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)
 };
 

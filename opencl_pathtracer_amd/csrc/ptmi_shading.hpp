@@ -15,7 +15,7 @@ struct Surface {
 template <class SceneT>
 __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, const Hit& hit, Surface& sf)
 {
-    const DShade* sh = &sc.shade[hit.tri];
+    const DShade* sh = &sc.shade[sc.tri_ids[hit.tri]];  // hit.tri is a record index
     const float4* s4 = reinterpret_cast<const float4*>(sh);
     // geometric normal: first float4 of a DTriPre record, last of a DTri record
     const V4 N = v4(reinterpret_cast<const float4*>(&sc.tris[hit.tri])[sc.tris_precomputed ? 0 : 3]);

@@ -196,6 +196,16 @@ def test_axis_aligned_rays_and_unordered_boxes_take_the_literal_box_test(kernel,
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
 
 
+def test_wide_record_addresses(scene_factory, monkeypatch):
+    """Record arrays of 4 GB or more need 64-bit byte offsets; the switch forces that path on a small scene."""
+    monkeypatch.setenv("PTMI_WIDE_RECORDS", "1")
+    sc = scene_factory("tris20k", 96, 64)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 96, 64, 6, 2)
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 96, 64, 6, 2)
+    assert counters == totals and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+
+
 def test_many_iterations_in_one_call_are_chunked(scene_factory):
     """ptmi_render splits a long range into launches of <= 16 iterations (staging array bound): same bits."""
     sc = scene_factory("cornell", 64, 48)
