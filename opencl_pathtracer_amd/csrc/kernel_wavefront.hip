@@ -130,8 +130,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     const uint32_t jobs_per_iteration = n_jobs / n_iterations;
 
     // ---- lane state -----------------------------------------------------------------------------
-    bool alive = true;       // may still receive work
-    bool need_path = true;   // no path in flight
+    // Whether a lane has a path in flight, or is done for good, is kept IN `cur` (REF_IDLE / REF_DEAD) so that the
+    // wave's three step masks come from three integer compares; the two bools below only live inside a path-logic trip.
+    bool alive = true, need_path = true;
     uint32_t gx = 0, gy = 0, it = first_iteration;
     // path
     int seed = 1;
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     float limit = 0;
     bool shadow = false, found = false;
     bool exact_boxes = false;  // this ray needs the literal box test (see box_hit_ordered)
-    uint32_t cur = REF_NONE, tri_i = 0, tri_end = 0;
+    uint32_t cur = REF_IDLE, tri_i = 0, tri_end = 0;
     uint32_t* sp = stack_floor;  // the top entry (the sentinel when the stack is empty)
     auto load_hit_point = [&]() {
         return v4(__uint_as_float(hit_mem[0 * kWfBlock]), __uint_as_float(hit_mem[1 * kWfBlock]),
@@ -215,11 +216,15 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // keeps the following traversal trips uniform), stragglers are not waited for.
     int wait_debt = 0;
     for (;;) {
-        const bool pending = !need_path && tri_i < tri_end;
-        const bool want_inner = !need_path && !pending && cur != REF_NONE;
-        const bool want_post = alive && (need_path || (!pending && cur == REF_NONE));
-        const unsigned long long m_t = __builtin_amdgcn_ballot_w64(pending), m_i = __builtin_amdgcn_ballot_w64(want_inner),
-                                 m_p = __builtin_amdgcn_ballot_w64(want_post);
+        // lane states: triangles pending (idle and dead lanes keep an empty range) / `cur` is an inner-node reference /
+        // neither: the query is finished (REF_NONE) or there is no path (REF_IDLE) -> path logic / REF_DEAD
+        const bool pending = tri_i < tri_end;
+        const bool has_node = cur < REF_DEAD;
+        const unsigned long long b_t = __builtin_amdgcn_ballot_w64(pending), b_n = __builtin_amdgcn_ballot_w64(has_node),
+                                 b_dead = __builtin_amdgcn_ballot_w64(cur == REF_DEAD);
+        const unsigned long long m_t = b_t, m_i = b_n & ~b_t, m_p = ~(b_t | b_n | b_dead);
+        const bool want_inner = !pending & has_node;
+        const bool want_post = !pending & !has_node & (cur != REF_DEAD);
         if ((m_t | m_i | m_p) == 0ull) break;
         const int n_t = __popcll(m_t), n_i = __popcll(m_i), n_p = __popcll(m_p);
 
@@ -233,6 +238,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             // ================================ P: path logic ========================================
             if (STATS) { trips_p++; lanes_p += n_p; }
             if (want_post) {
+                need_path = cur == REF_IDLE;
+                alive = true;
                 bool end_path = false;
                 bool start_shadow = false, do_scatter = false;
                 Hit hit;
@@ -361,6 +368,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         finish_path();  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
                     }
                 }
+                if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
             }
         } else {
             // ===================== traversal trip: EVERY traversing lane takes one step ====================

@@ -41,6 +41,8 @@ constexpr uint32_t REF_COUNT_BIG = 7;
 constexpr uint32_t REF_INDEX_MASK_INNER = 0x3FFFFFFFu;
 constexpr uint32_t REF_INDEX_MASK_LEAF = 0x07FFFFFFu;
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // traversal finished (never a valid ref: leaf+empty+count 7 + all ones)
+constexpr uint32_t REF_IDLE = 0xFFFFFFFEu;  // wavefront kernel: the lane has no path in flight
+constexpr uint32_t REF_DEAD = 0xFFFFFFFDu;  // wavefront kernel: the job queue is empty, the lane is done
 
 struct DNode {
     float lo1[3], hi1[3];  // son1Id's trianglesAABB pMin/pMax xyz
