@@ -52,9 +52,6 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 // mix 4K): 3: 415, 4: 500 / 2731 / 1382, 5: 533 / 2708 / 1375, 6: 409.
 #define PTMI_WF_MIN_WAVES 5
 #endif
-#ifndef PTMI_WF_LINE_MATES
-#define PTMI_WF_LINE_MATES 0
-#endif
 constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
@@ -215,179 +212,41 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // the debt crosses a bound: bursts of finishers are served together (and leave path logic in lockstep, which
     // keeps the following traversal trips uniform), stragglers are not waited for.
     int wait_debt = 0;
-    for (;;) {
-        // lane states: triangles pending (idle and dead lanes keep an empty range) / `cur` is an inner-node reference /
-        // neither: the query is finished (REF_NONE) or there is no path (REF_IDLE) -> path logic / REF_DEAD
-        const bool pending = tri_i < tri_end;
+    // lane states: triangles pending (idle and dead lanes keep an empty range) / `cur` is an inner-node reference /
+    // neither: the query is finished (REF_NONE) or there is no path (REF_IDLE) -> path logic / REF_DEAD
+    bool pending, want_inner, want_post;
+    int n_t, n_i, n_p;
+    bool any_lane;
+    auto survey = [&]() {
+        pending = tri_i < tri_end;
         const bool has_node = cur < REF_DEAD;
         const unsigned long long b_t = __builtin_amdgcn_ballot_w64(pending), b_n = __builtin_amdgcn_ballot_w64(has_node),
                                  b_dead = __builtin_amdgcn_ballot_w64(cur == REF_DEAD);
         const unsigned long long m_t = b_t, m_i = b_n & ~b_t, m_p = ~(b_t | b_n | b_dead);
-        const bool want_inner = !pending & has_node;
-        const bool want_post = !pending & !has_node & (cur != REF_DEAD);
-        if ((m_t | m_i | m_p) == 0ull) break;
-        const int n_t = __popcll(m_t), n_i = __popcll(m_i), n_p = __popcll(m_p);
-
-        // Progress guarantee: the chosen branch always has at least one lane (the loop has left above when
-        // all three masks are empty), so every trip advances some lane and the wave drains.
-        // (Keep the condition inline: hoisting it into bool variables makes hipcc 7.2 structure the loop
-        // differently and costs 36 VGPRs = one wave per SIMD; check `make resources` after every edit.)
+        want_inner = !pending & has_node;
+        want_post = !pending & !has_node & (cur != REF_DEAD);
+        any_lane = (m_t | m_i | m_p) != 0ull;
+        n_t = __popcll(m_t); n_i = __popcll(m_i); n_p = __popcll(m_p);
         wait_debt += n_p;
-        if ((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0)) {
-            wait_debt = 0;
-            // ================================ P: path logic ========================================
-            if (STATS) { trips_p++; lanes_p += n_p; }
-            if (want_post) {
-                need_path = cur == REF_IDLE;
-                alive = true;
-                bool end_path = false;
-                bool start_shadow = false, do_scatter = false;
-                Hit hit;
-                hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
-                if (!need_path) {
-                    hit.point = load_hit_point();
-                    if (!shadow) {
-                        // closest-hit query finished (FullKernel.cl:1252-1288)
-                        if (found) {
-                            hit.s = __uint_as_float(hit_mem[4 * kWfBlock]); hit.t = __uint_as_float(hit_mem[5 * kWfBlock]);
-                            hit.tri = hit_mem[6 * kWfBlock]; hit.front = hit_mem[7 * kWfBlock] != 0;
-                            load_surface(sc, r, hit, sf);
-                            cam_d = r.d;
-                            direct = v4(0, 0, 0, 0);
-                            light_idx = 0;
-                            if (sc.n_lights > 0) start_shadow = true;
-                            else do_scatter = true;
-                        } else {
-                            radiance = radiance + (sky_color(cold_scene().sky, sc.texels, r.d) * transfer);
-                            end_path = true;
-                        }
-                    } else {
-                        // shadow query finished (Scene_ComputeDirectIllumination, :944-947)
-                        if (!found) {
-                            const ptmi_light light = sc.lights[light_idx];
-                            const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
-                            direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
-                        }
-                        light_idx++;
-                        if (light_idx < sc.n_lights) start_shadow = true;
-                        else do_scatter = true;
-                    }
-                    if (start_shadow) {
-                        // :932-944: ray from the hit point (no offset) towards light `light_idx`
-                        const ptmi_light light = sc.lights[light_idx];
-                        const bool directional = light.type == PTMI_LIGHT_DIRECTIONNAL;
-                        const V4 full = directional ? -v4(light.direction) : v4(light.position) - hit.point;
-                        r.o = hit.point;
-                        ray_set_direction(r, full);
-                        limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
-                        shadow = true;
-                        start_query();
-                        n_shadow++;
-                    }
-                    if (do_scatter) {
-                        r.d = cam_d;
-                        radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
-                        reflection++;
-                        shadow = false;
-                        const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // :1296-1304
-                        const float m = transfer.x < m_yz ? m_yz : transfer.x;
-                        if (m <= kMinContribution || reflection >= sc.max_depth) {
-                            end_path = true;
-                        } else {
-                            limit = INFINITY;
-                            start_query();
-                            n_seg++;
-                        }
-                    }
-                    if (end_path) finish_path();
-                }
-
-                // ---- job hand-out: one atomic per wave for all lanes that ran dry -----------------
-                bool got_job = false;
-                const bool want_job = need_path;
-                const unsigned long long m_job = __ballot(want_job);
-                if (want_job) {
-                    const int leader = __ffsll((long long)m_job) - 1;
-                    const uint32_t rank = __popcll(m_job & ((1ull << (tid & 63u)) - 1ull));
-                    uint32_t base = 0;
-                    if ((int)(tid & 63u) == leader) base = atomicAdd(job_counter, (uint32_t)__popcll(m_job));
-                    base = __shfl(base, leader);
-                    const uint32_t job = base + rank;
-                    if (job >= n_jobs) {
-                        alive = false;
-                    } else {
-                        // iteration-major; inside an iteration 8x8 tiles in row-major order
-                        const uint32_t it_local = job / jobs_per_iteration;
-                        const uint32_t rem = job - it_local * jobs_per_iteration;
-                        const uint32_t tile = rem >> 6, in_tile = rem & 63u;
-                        gx = (tile % tiles_x) * 8u + (in_tile & 7u);
-                        gy = (tile / tiles_x) * 8u + (in_tile >> 3);
-                        it = first_iteration + it_local;
-                        got_job = gx < sc.width && gy < sc.height;  // edge tiles: pixel outside the image, ask again
-                    }
-                }
-
-                // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
-                if (got_job) {
-                    seed = lcg_seed(gx, gy, sc.width, sc.height, it);
-                    draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
-                    {
-                        const DScene& cs = cold_scene();  // camera: only needed here, once per path
-                        r.o = v4(cs.cam_pos);
-                        ray_set_direction(r, (v4(cs.cam_dir) + (v4(cs.cam_right) * sample_x)) + (v4(cs.cam_up) * sample_y));
-                    }
-                    radiance = v4(0, 0, 0, 0);
-                    transfer = v4(1, 1, 1, 1);
-                    reflection = 0; p_bbx = 0; p_tri = 0;
-                    in_water = false;
-                    shadow = false;
-                    found = false;
-                    need_path = false;
-                    bool skip = false;
-                    if (SS && it > 5u) {
-                        // superSamplingStopCriteria, FullKernel.cl:1152-1172 (called at :1219-1222, one launch per
-                        // iteration so the accumulators hold iterations < it); draws one random number
-                        const DScene& cs = cold_scene();
-                        const uint32_t off = gy * sc.width + gx;
-                        const float n = cs.image_ray_nb[off];
-                        const float4 vv = reinterpret_cast<const float4*>(cs.image_v)[off];
-                        const float sigma2_n = fmaxf(fmaxf(vv.x / n, vv.y / n), vv.z / n);
-                        uint32_t idx = (uint32_t)n;
-                        if (idx > 1000u) idx = 1000u;  // the reference indexes past its 1001-entry table here
-                        skip = (double)lcg_random(seed) > (double)(100 * sigma2_n / cs.x2inv[idx]) + 0.05;
-                    }
-                    if (skip) {
-                        cold_scene().stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
-                        need_path = true;
-                    } else
-                    if (sc.max_depth > 0) {
-                        limit = INFINITY;
-                        start_query();
-                        n_seg++;
-                    } else {
-                        finish_path();  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
-                    }
-                }
-                if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
-            }
-        } else {
-            // ===================== traversal trip: EVERY traversing lane takes one step ====================
-            // A DNode and a DTri are both one aligned 64-byte record, so node lanes and triangle lanes issue
-            // the same four dwordx4 loads and the wave pays the memory latency once for both kinds.
-            if (STATS) {
-                trips_i += n_i ? 1u : 0u; lanes_i += n_i;
-                trips_t += n_t ? 1u : 0u; lanes_t += n_t;
-            }
-            // LINE-MATE SUB-STEPS.  The integrator is bound by the 64 or so L1 misses a CU can have in flight (time =
-            // sum of miss latencies / 64 per CU, tools/microbench/record_fetch.hip), and the L1 is far too small to keep
-            // a line until the lane's next trip.  So a lane whose NEXT record lies in the 128-byte line it has just
-            // fetched - the second triangle of an aligned pair, or son1 stored right behind its (even-numbered) parent -
-            // takes that step at once, while the line is still in the L1; the other lanes sit the sub-step out.
-            bool go = pending || want_inner;
-            bool is_tri = pending;
+    };
+    // Loop nest: path logic in the outer loop, traversal trips in an inner loop of their own, so that the traversal
+    // state is loop-carried through ONE small loop (as one if/else in one loop the two big branches were merged through
+    // temporaries: 16 v_mov per trip).  Progress: a trip or a path-logic pass only runs with at least one lane wanting
+    // it (the inner loop leaves as soon as nothing can traverse), so every pass advances some lane and the wave drains.
+    for (;;) {
+        survey();
+        if (!any_lane) break;
+        if (!((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0))) {
             for (;;) {
-                const uint32_t line_key = is_tri ? ((tri_i >> 1) | 0x80000000u) : ((cur & REF_INDEX_MASK_INNER) >> 1);
-                if (go) {
+                // ===================== traversal trip: EVERY traversing lane takes one step ====================
+                // A DNode and a DTri are both one aligned 64-byte record, so node lanes and triangle lanes issue
+                // the same four dwordx4 loads and the wave pays the memory latency once for both kinds.
+                if (STATS) {
+                    trips_i += n_i ? 1u : 0u; lanes_i += n_i;
+                    trips_t += n_t ? 1u : 0u; lanes_t += n_t;
+                }
+                const bool is_tri = pending;
+                if (pending || want_inner) {
                     // nodes and triangles live in one array of 64-byte records (nodes == tris): scalar base + 32-bit
                     // byte offset while the array is below 4 GB (the shift drops a node reference's flag bits)
                     float4 a, b, c, d;
@@ -463,18 +322,145 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         sp = below < stack_floor ? stack_floor : below;
                     }
                 }
-#if PTMI_WF_LINE_MATES
-                const bool next_tri = tri_i < tri_end;
-                const bool next_inner = !next_tri && cur != REF_NONE;
-                const uint32_t next_key = next_tri ? ((tri_i >> 1) | 0x80000000u) : ((cur & REF_INDEX_MASK_INNER) >> 1);
-                go = go & (next_tri | next_inner) & (next_key == line_key);
-                if (__builtin_amdgcn_ballot_w64(go) == 0ull) break;
-                is_tri = next_tri;
-#else
-                (void)line_key;
-                break;
-#endif
+                    survey();
+                if ((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0)) break;
             }
+        }
+        wait_debt = 0;
+        // ================================ P: path logic ========================================
+        if (STATS) { trips_p++; lanes_p += n_p; }
+        if (want_post) {
+            need_path = cur == REF_IDLE;
+            alive = true;
+            bool end_path = false;
+            bool start_shadow = false, do_scatter = false;
+            Hit hit;
+            hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
+            if (!need_path) {
+                hit.point = load_hit_point();
+                if (!shadow) {
+                    // closest-hit query finished (FullKernel.cl:1252-1288)
+                    if (found) {
+                        hit.s = __uint_as_float(hit_mem[4 * kWfBlock]); hit.t = __uint_as_float(hit_mem[5 * kWfBlock]);
+                        hit.tri = hit_mem[6 * kWfBlock]; hit.front = hit_mem[7 * kWfBlock] != 0;
+                        load_surface(sc, r, hit, sf);
+                        cam_d = r.d;
+                        direct = v4(0, 0, 0, 0);
+                        light_idx = 0;
+                        if (sc.n_lights > 0) start_shadow = true;
+                        else do_scatter = true;
+                    } else {
+                        radiance = radiance + (sky_color(cold_scene().sky, sc.texels, r.d) * transfer);
+                        end_path = true;
+                    }
+                } else {
+                    // shadow query finished (Scene_ComputeDirectIllumination, :944-947)
+                    if (!found) {
+                        const ptmi_light light = sc.lights[light_idx];
+                        const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
+                        direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
+                    }
+                    light_idx++;
+                    if (light_idx < sc.n_lights) start_shadow = true;
+                    else do_scatter = true;
+                }
+                if (start_shadow) {
+                    // :932-944: ray from the hit point (no offset) towards light `light_idx`
+                    const ptmi_light light = sc.lights[light_idx];
+                    const bool directional = light.type == PTMI_LIGHT_DIRECTIONNAL;
+                    const V4 full = directional ? -v4(light.direction) : v4(light.position) - hit.point;
+                    r.o = hit.point;
+                    ray_set_direction(r, full);
+                    limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
+                    shadow = true;
+                    start_query();
+                    n_shadow++;
+                }
+                if (do_scatter) {
+                    r.d = cam_d;
+                    radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
+                    reflection++;
+                    shadow = false;
+                    const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // :1296-1304
+                    const float m = transfer.x < m_yz ? m_yz : transfer.x;
+                    if (m <= kMinContribution || reflection >= sc.max_depth) {
+                        end_path = true;
+                    } else {
+                        limit = INFINITY;
+                        start_query();
+                        n_seg++;
+                    }
+                }
+                if (end_path) finish_path();
+            }
+
+            // ---- job hand-out: one atomic per wave for all lanes that ran dry -----------------
+            bool got_job = false;
+            const bool want_job = need_path;
+            const unsigned long long m_job = __ballot(want_job);
+            if (want_job) {
+                const int leader = __ffsll((long long)m_job) - 1;
+                const uint32_t rank = __popcll(m_job & ((1ull << (tid & 63u)) - 1ull));
+                uint32_t base = 0;
+                if ((int)(tid & 63u) == leader) base = atomicAdd(job_counter, (uint32_t)__popcll(m_job));
+                base = __shfl(base, leader);
+                const uint32_t job = base + rank;
+                if (job >= n_jobs) {
+                    alive = false;
+                } else {
+                    // iteration-major; inside an iteration 8x8 tiles in row-major order
+                    const uint32_t it_local = job / jobs_per_iteration;
+                    const uint32_t rem = job - it_local * jobs_per_iteration;
+                    const uint32_t tile = rem >> 6, in_tile = rem & 63u;
+                    gx = (tile % tiles_x) * 8u + (in_tile & 7u);
+                    gy = (tile / tiles_x) * 8u + (in_tile >> 3);
+                    it = first_iteration + it_local;
+                    got_job = gx < sc.width && gy < sc.height;  // edge tiles: pixel outside the image, ask again
+                }
+            }
+
+            // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
+            if (got_job) {
+                seed = lcg_seed(gx, gy, sc.width, sc.height, it);
+                draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
+                {
+                    const DScene& cs = cold_scene();  // camera: only needed here, once per path
+                    r.o = v4(cs.cam_pos);
+                    ray_set_direction(r, (v4(cs.cam_dir) + (v4(cs.cam_right) * sample_x)) + (v4(cs.cam_up) * sample_y));
+                }
+                radiance = v4(0, 0, 0, 0);
+                transfer = v4(1, 1, 1, 1);
+                reflection = 0; p_bbx = 0; p_tri = 0;
+                in_water = false;
+                shadow = false;
+                found = false;
+                need_path = false;
+                bool skip = false;
+                if (SS && it > 5u) {
+                    // superSamplingStopCriteria, FullKernel.cl:1152-1172 (called at :1219-1222, one launch per
+                    // iteration so the accumulators hold iterations < it); draws one random number
+                    const DScene& cs = cold_scene();
+                    const uint32_t off = gy * sc.width + gx;
+                    const float n = cs.image_ray_nb[off];
+                    const float4 vv = reinterpret_cast<const float4*>(cs.image_v)[off];
+                    const float sigma2_n = fmaxf(fmaxf(vv.x / n, vv.y / n), vv.z / n);
+                    uint32_t idx = (uint32_t)n;
+                    if (idx > 1000u) idx = 1000u;  // the reference indexes past its 1001-entry table here
+                    skip = (double)lcg_random(seed) > (double)(100 * sigma2_n / cs.x2inv[idx]) + 0.05;
+                }
+                if (skip) {
+                    cold_scene().stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
+                    need_path = true;
+                } else
+                if (sc.max_depth > 0) {
+                    limit = INFINITY;
+                    start_query();
+                    n_seg++;
+                } else {
+                    finish_path();  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
+                }
+            }
+            if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
         }
     }
 

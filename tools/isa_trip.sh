@@ -8,29 +8,21 @@ mkdir -p /tmp/isa
   -Iopencl_pathtracer_amd/csrc "$@" --cuda-device-only -S opencl_pathtracer_amd/csrc/kernel_wavefront.hip -o /tmp/isa/wf.s 2>/dev/null
 python3 - <<'PY'
 import re
+from collections import Counter
 t=open('/tmp/isa/wf.s').read().split('\n')
 start=[i for i,l in enumerate(t) if l.startswith('_ZN8ptmi_dev23render_wavefront_kernelILb0ELb1ELb0E')][0]
 end=[i for i,l in enumerate(t) if i>start and l.startswith('.Lfunc_end')][0]
 k=t[start:end]
 open('/tmp/isa/k.s','w').write('\n'.join(k))
-# the trip: from the loop header to the end of the block that holds the first run of four dwordx4 loads
-loads=[i for i,l in enumerate(k) if 'global_load_dwordx4' in l]
-first=loads[0]
-hdr=max(i for i,l in enumerate(k[:first]) if 'Loop Header' in l)
-# end: first label after the loads whose block starts the path logic: heuristic = next 'global_load_dwordx4' run minus nothing
-nxt=[i for i,l in enumerate(k) if i>first+3 and 's_cbranch_vccnz' in l][0]
-target=k[nxt].split()[1]
-tl=[i for i,l in enumerate(k) if l.startswith(target+':')][0]
-te=[i for i,l in enumerate(k) if i>tl and 's_branch' in l][0]
-body=k[hdr:nxt]+k[tl:te]
-ins=[l.split()[0] for l in body if re.match(r'\s+[a-z]',l)]
-from collections import Counter
+# the traversal trips are the only depth-2 loop of the kernel: count the instructions of its blocks
+depth2=False; ins=[]
+for l in k:
+    if re.match(r'(\.LBB|; %bb\.)',l):
+        depth2 = 'Depth=2' in l
+    elif depth2 and re.match(r'\s+[a-z]',l):
+        ins.append(l.split()[0])
 c=Counter(ins)
-valu=sum(n for i,n in c.items() if i.startswith('v_'))
-mov=sum(n for i,n in c.items() if i.startswith('v_mov'))
-print('lines %d..%d of /tmp/isa/k.s: VALU %d (v_mov %d, v_cndmask %d, v_cmp %d)  SALU %d  LDS %d  VMEM %d'%(hdr,nxt,valu,mov,
-      sum(n for i,n in c.items() if i.startswith('v_cndmask')),sum(n for i,n in c.items() if i.startswith('v_cmp')),
-      sum(n for i,n in c.items() if i.startswith('s_')),sum(n for i,n in c.items() if i.startswith('ds_')),
-      sum(n for i,n in c.items() if i.startswith('global_') or i.startswith('scratch_'))))
+tot=lambda p: sum(n for i,n in c.items() if i.startswith(p))
+print('traversal loop: VALU %d (v_mov %d, v_cndmask %d, v_cmp %d)  SALU %d  LDS %d  VMEM %d'%(tot('v_'),tot('v_mov'),tot('v_cndmask'),tot('v_cmp'),tot('s_'),tot('ds_'),tot('global_')+tot('scratch_')))
 PY
 grep -A12 "Function Name: _ZN8ptmi_dev23render_wavefront_kernelILb0ELb1ELb0E" /dev/null 2>/dev/null || true
