@@ -141,8 +141,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     Ray r;
     r.o = v4(0, 0, 0, 0); r.d = v4(0, 0, 0, 0); r.ix = r.iy = r.iz = 0;
     float limit = 0;
-    bool shadow = false, found = false;
+    bool shadow = false;
     bool exact_boxes = false;  // this ray needs the literal box test (see box_hit_ordered)
+    bool wave_exact = true;    // ... and so does some ray of this wave (wave-uniform, refreshed after every path-logic pass)
     uint32_t cur = REF_IDLE, tri_i = 0, tri_end = 0;
     uint32_t* sp = stack_floor;  // the top entry (the sentinel when the stack is empty)
     auto load_hit_point = [&]() {
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // the range is free.
     auto start_query = [&]() {
         cur = sc.root_ref; sp = stack_floor; tri_i = tri_end = 0;
-        found = false;
+        hit_mem[7 * kWfBlock] = 0;  // "found" lives in the hit record: bit 1 of its last word (bit 0: front side)
         exact_boxes = !(sc.boxes_ordered && ray_slabs_are_ordered(r));
         if (cur & REF_LEAF) {  // the whole scene is one leaf
             decode_leaf(sc, cur, tri_i, tri_end);
@@ -262,34 +263,36 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     if (is_tri) {
                         // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
                         p_tri++;
-                        bool accepted = false;
                         tri_test<PRE>(a, b, c, d, r, limit, [&](const V4& q, float s, float t, bool front, float nsd) {
-                            accepted = true;
                             limit = nsd;
                             if (!shadow) {  // closest hit so far: the record path logic will shade from
                                 hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
                                 hit_mem[2 * kWfBlock] = __float_as_uint(q.z); hit_mem[3 * kWfBlock] = __float_as_uint(q.w);
                                 hit_mem[4 * kWfBlock] = __float_as_uint(s); hit_mem[5 * kWfBlock] = __float_as_uint(t);
-                                hit_mem[6 * kWfBlock] = tri_i; hit_mem[7 * kWfBlock] = front ? 1u : 0u;
+                                hit_mem[6 * kWfBlock] = tri_i; hit_mem[7 * kWfBlock] = front ? 3u : 2u;
+                            } else {
+                                // any hit ends a shadow query (:724-727): empty the triangle range, drop the pending
+                                // node.  Written as in-place moves (tied asm operands) so that these two registers
+                                // are not merged back through the early exits with a select on every trip.
+                                hit_mem[7 * kWfBlock] = 2u;
+                                asm volatile("v_mov_b32 %0, %1" : "+v"(tri_end) : "v"(tri_i));
+                                asm volatile("v_mov_b32 %0, -1" : "+v"(cur));
                             }
                         });
-                        found |= accepted;
-                        const bool stop = accepted & shadow;  // any hit ends a shadow query (:724-727)
-                        tri_end = stop ? tri_i : tri_end;
-                        cur = stop ? REF_NONE : cur;
-                        sp = stop ? stack_floor : sp;
                         tri_i++;
                     } else {
                         // ---- one inner-node step (:660-697)
                         const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
                         const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
                         const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
-                        const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
-                        const bool fwd = da > 0;
+                        // dir[cutAxis] > 0 (:663) from the three sign masks the box tests need anyway: lane-mask logic
+                        const bool a0 = axis == 0, a1 = axis == 1;
+                        const bool fwd = (a0 & (r.d.x > 0)) | (a1 & (r.d.y > 0)) | (!(a0 | a1) & (r.d.z > 0));
                         bool h1, h2;
-                        if (__builtin_amdgcn_ballot_w64(exact_boxes) == 0ull) {  // wave-uniform: nearly always
-                            h1 = box_hit_ordered(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
-                            h2 = box_hit_ordered(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+                        if (!wave_exact) {  // wave-uniform: nearly always
+                            // (an empty child needs no flag test here: the upload stores it as an inverted infinite box)
+                            h1 = box_hit_ordered(lo1, hi1, r, limit);
+                            h2 = box_hit_ordered(lo2, hi2, r, limit);
                         } else {
                             h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
                             h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
@@ -299,11 +302,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         // far one; push the far one when both were hit.  In terms of son1/son2:
                         const uint32_t far_ref = fwd ? ref2 : ref1;
                         const bool both = h1 & h2;
-                        const bool take1 = fwd ? h1 : !h2;
                         // push without a branch (see the LDS layout above)
                         sp[kWfBlock] = far_ref;
                         sp += both ? kWfBlock : 0;
-                        cur = take1 ? ref1 : ref2;
+                        cur = fwd ? (h1 ? ref1 : ref2) : (h2 ? ref2 : ref1);  // near child if it was hit, else the far one
                         need_pop = !(h1 | h2);
                     }
                     // ---- common tail of both step kinds, branch-free pops (an LDS read every lane can afford)
@@ -338,11 +340,12 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
             if (!need_path) {
                 hit.point = load_hit_point();
+                const bool found = (hit_mem[7 * kWfBlock] & 2u) != 0;
                 if (!shadow) {
                     // closest-hit query finished (FullKernel.cl:1252-1288)
                     if (found) {
                         hit.s = __uint_as_float(hit_mem[4 * kWfBlock]); hit.t = __uint_as_float(hit_mem[5 * kWfBlock]);
-                        hit.tri = hit_mem[6 * kWfBlock]; hit.front = hit_mem[7 * kWfBlock] != 0;
+                        hit.tri = hit_mem[6 * kWfBlock]; hit.front = (hit_mem[7 * kWfBlock] & 1u) != 0;
                         load_surface(sc, r, hit, sf);
                         cam_d = r.d;
                         direct = v4(0, 0, 0, 0);
@@ -433,7 +436,6 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 reflection = 0; p_bbx = 0; p_tri = 0;
                 in_water = false;
                 shadow = false;
-                found = false;
                 need_path = false;
                 bool skip = false;
                 if (SS && it > 5u) {
@@ -462,6 +464,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             }
             if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
         }
+        wave_exact = __builtin_amdgcn_ballot_w64(exact_boxes) != 0ull;  // finished lanes keep a stale flag: conservative
     }
 
     atomicAdd(&block_counters[C_PATHS], (unsigned long long)n_paths);

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -281,7 +282,7 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         d.hi1[0] = b1.p_max.x; d.hi1[1] = b1.p_max.y; d.hi1[2] = b1.p_max.z;
         d.lo2[0] = b2.p_min.x; d.lo2[1] = b2.p_min.y; d.lo2[2] = b2.p_min.z;
         d.hi2[0] = b2.p_max.x; d.hi2[1] = b2.p_max.y; d.hi2[2] = b2.p_max.z;
-        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.pad = 0;  // inner children: index patched in when they are emitted
+        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.axis_bit = 1u << n.cut_axis;  // inner children: index patched in when they are emitted
         // the short slab test (box_hit_ordered) needs finite, ordered boxes; anything else keeps the literal form
         for (int k = 0; k < 3; k++) {
             if (!(r1 & REF_EMPTY) && !(std::isfinite(d.lo1[k]) && std::isfinite(d.hi1[k]) && d.lo1[k] <= d.hi1[k])) out.boxes_ordered = false;
@@ -294,6 +295,15 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         if (!c1.is_leaf) todo.push_back({n.son1_id, (uint32_t)self, 0, child_depth});
     }
     if (out.recs.empty()) { out.recs.emplace_back(); out.tri_ids.push_back(0xFFFFFFFFu); }  // a root leaf without triangles
+    // box_hit_ordered tests no isEmpty flag: an empty child is stored as an inverted infinite box (never hit)
+    if (out.boxes_ordered)
+        for (size_t i = 0; i < out.recs.size(); i++) {
+            if (out.tri_ids[i] != 0xFFFFFFFFu) continue;
+            DNode& d = node_at(i);
+            const float inf = std::numeric_limits<float>::infinity();
+            if (d.ref1 & REF_EMPTY) for (int k = 0; k < 3; k++) { d.lo1[k] = inf; d.hi1[k] = -inf; }
+            if (d.ref2 & REF_EMPTY) for (int k = 0; k < 3; k++) { d.lo2[k] = inf; d.hi2[k] = -inf; }
+        }
     // the traversal stack has 30 entries (FullKernel.cl:627); the reference refuses deeper trees (PathTracer.cpp:54-58)
     if (out.max_depth >= PTMI_BVH_MAX_DEPTH)
         return fail(ctx, PTMI_ERR_LIMIT, "bvh depth " + std::to_string(out.max_depth) + " >= 30");

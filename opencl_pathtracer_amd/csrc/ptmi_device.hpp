@@ -130,16 +130,21 @@ __device__ __forceinline__ bool box_hit(const float lo[3], const float hi[3], bo
 //   the distance test  !(tmin < 0) && tmin > limit  (:136)                   ==  tmin > limit   (limit is never negative)
 // Rays with a zero direction component (reciprocal +-inf: 0 * inf = NaN at a box plane through the origin, and the
 // reference's "+0 fails every box" quirk) never get here: they keep the literal form above.
-__device__ __forceinline__ bool box_hit_ordered(const float lo[3], const float hi[3], bool is_empty, const Ray& r, float limit)
+// An EMPTY box (isEmpty: never hit, FullKernel.cl:68) is stored for this form as lo = +inf, hi = -inf, which gives
+// tmin = +inf > tmax = -inf for either direction sign, so no flag has to be tested.
+typedef float ptmi_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool box_hit_ordered(const float lo[3], const float hi[3], const Ray& r, float limit)
 {
+    // two-wide arithmetic spelled out (v_pk_add_f32 / v_pk_mul_f32: same IEEE operations, half the instructions):
+    // (x, y) of the near planes, (x, y) of the far planes, and (near, far) of z
     const bool px = r.d.x > 0, py = r.d.y > 0, pz = r.d.z > 0;
-    const float txmin = ((px ? lo[0] : hi[0]) - r.o.x) * r.ix, txmax = ((px ? hi[0] : lo[0]) - r.o.x) * r.ix;
-    const float tymin = ((py ? lo[1] : hi[1]) - r.o.y) * r.iy, tymax = ((py ? hi[1] : lo[1]) - r.o.y) * r.iy;
-    const float tzmin = ((pz ? lo[2] : hi[2]) - r.o.z) * r.iz, tzmax = ((pz ? hi[2] : lo[2]) - r.o.z) * r.iz;
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(txmin, tymin), tzmin);
-    const float tmax = __builtin_fminf(__builtin_fminf(txmax, tymax), tzmax);
-    const bool miss = (tmax < 0) | (tmin > tmax) | (tmin > limit);
-    return !(miss | is_empty);
+    const ptmi_f2 o_xy = {r.o.x, r.o.y}, i_xy = {r.ix, r.iy}, o_zz = {r.o.z, r.o.z}, i_zz = {r.iz, r.iz};
+    const ptmi_f2 near_xy = {px ? lo[0] : hi[0], py ? lo[1] : hi[1]}, far_xy = {px ? hi[0] : lo[0], py ? hi[1] : lo[1]};
+    const ptmi_f2 z_nf = {pz ? lo[2] : hi[2], pz ? hi[2] : lo[2]};
+    const ptmi_f2 tn = (near_xy - o_xy) * i_xy, tf = (far_xy - o_xy) * i_xy, tz = (z_nf - o_zz) * i_zz;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(tn.x, tn.y), tz.x);
+    const float tmax = __builtin_fminf(__builtin_fminf(tf.x, tf.y), tz.y);
+    return !((tmax < 0) | (tmin > tmax) | (tmin > limit));
 }
 __device__ __forceinline__ bool ray_slabs_are_ordered(const Ray& r)
 {
