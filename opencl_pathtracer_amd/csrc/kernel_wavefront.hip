@@ -41,10 +41,11 @@ namespace ptmi_dev {
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #ifndef PTMI_WF_WAIT_DEBT
-// lane-trips of waiting a wave tolerates before it spends a trip on path logic.  Measured on MI355X
-// (Msamples/s, 1M triangles / Cornell box, both 1080p): 48: 471 / 1127, 192: 484 / 2002, 512: 479 / 2729,
-// 1024: 463 / 3004; a fixed threshold of 8 lanes: 474 / 743.
-#define PTMI_WF_WAIT_DEBT 512
+// lane-trips of waiting a wave tolerates before it spends a pass on path logic.  Measured on MI355X, one box, final r01
+// kernel (Msamples/s: 1M triangles 1080p / Cornell box 1080p / material mix 4K):
+//   512: 673 / 2715 / 1444    768: 679    1024: 681 / 3003 / 1647    1536: 676 / 3017 / 1677    2048: 666
+// (a fixed threshold of 8 waiting lanes instead of a debt measured 474 / 743 with an earlier build)
+#define PTMI_WF_WAIT_DEBT 1024
 #endif
 #ifndef PTMI_WF_MIN_WAVES
 // waves per SIMD the register allocator must fit (5 -> 96 VGPRs, the overflow spills to scratch inside the path-logic

@@ -7,6 +7,7 @@
 //   mode 0: per-lane        - lane L reads its own record with 4 x dwordx4                (4 accesses / record)
 //   mode 1: quad-cooperative - the 4 lanes of a quad read ONE record per instruction, 16 B each (contiguous 64 B)
 //   mode 2: pair-cooperative - 2 lanes read 32 contiguous bytes of one record per instruction
+//   mode 3: quad-cooperative with non-temporal loads (no L1 allocation), mode 4: per-lane with non-temporal loads
 // Every mode reads the same 64 bytes per lane per iteration; a checksum keeps the loads alive.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -46,6 +47,29 @@ __global__ void __launch_bounds__(256, 8) fetch(const float4* __restrict__ recs,
                 if ((int)q == k) t = sum;
             }
             acc += t;
+        } else if (MODE == 3 || MODE == 4) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f* base = reinterpret_cast<const v4f*>(recs);
+            if (MODE == 4) {
+                const v4f* p = base + (size_t)idx * 4;
+                const v4f a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1),
+                          c = __builtin_nontemporal_load(p + 2), d = __builtin_nontemporal_load(p + 3);
+                acc += a.x + b.y + c.z + d.w;
+            } else {
+                const uint32_t q = lane & 3u;
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t idx_k = __shfl(idx, (int)((lane & ~3u) + k));
+                    const v4f v = __builtin_nontemporal_load(base + (size_t)idx_k * 4 + q);
+                    const float e = q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
+                    float sum = e;
+                    sum += __shfl_xor(sum, 1);
+                    sum += __shfl_xor(sum, 2);
+                    if ((int)q == k) t = sum;
+                }
+                acc += t;
+            }
         } else {
             const uint32_t h = lane & 1u;
             float t = 0.f;
@@ -79,14 +103,15 @@ int main(int argc, char** argv)
     CHECK(hipMemcpy(recs, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    std::vector<float> sums(3);
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         float best = 1e30f;
         for (int rep = 0; rep < 3; rep++) {
             CHECK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(fetch<0>, dim3(blocks), dim3(256), 0, 0, recs, n_recs, iters, out);
             if (mode == 1) hipLaunchKernelGGL(fetch<1>, dim3(blocks), dim3(256), 0, 0, recs, n_recs, iters, out);
             if (mode == 2) hipLaunchKernelGGL(fetch<2>, dim3(blocks), dim3(256), 0, 0, recs, n_recs, iters, out);
+            if (mode == 3) hipLaunchKernelGGL(fetch<3>, dim3(blocks), dim3(256), 0, 0, recs, n_recs, iters, out);
+            if (mode == 4) hipLaunchKernelGGL(fetch<4>, dim3(blocks), dim3(256), 0, 0, recs, n_recs, iters, out);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
