@@ -53,6 +53,10 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 // mix 4K): 3: 415, 4: 500 / 2731 / 1382, 5: 533 / 2708 / 1375, 6: 409.
 #define PTMI_WF_MIN_WAVES 5
 #endif
+#ifndef PTMI_WF_QUEUES
+#define PTMI_WF_QUEUES 8
+#endif
+constexpr int kQueues = PTMI_WF_QUEUES;  // job queues (image stripes), one per XCD group of workgroups
 constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
@@ -125,7 +129,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     uint32_t* const hit_mem = &stack_mem[tid];
     const uint32_t tiles_x = (sc.width + 7u) >> 3;
     const bool owns_pixel = sc.sampler != PTMI_SAMPLER_RANDOM;
-    const uint32_t jobs_per_iteration = n_jobs / n_iterations;
+    const uint32_t n_tiles = (n_jobs / n_iterations) >> 6;
+    uint32_t q_cur = blockIdx.x % (uint32_t)kQueues, q_done = 0;  // wave-uniform: current queue, queues seen empty
 
     // ---- lane state -----------------------------------------------------------------------------
     // Whether a lane has a path in flight, or is done for good, is kept IN `cur` (REF_IDLE / REF_DEAD) so that the
@@ -332,6 +337,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         wait_debt = 0;
         // ================================ P: path logic ========================================
         if (STATS) { trips_p++; lanes_p += n_p; }
+        // (three divergent regions with the wave-uniform job hand-out between them: the queue state must stay scalar)
         if (want_post) {
             need_path = cur == REF_IDLE;
             alive = true;
@@ -397,32 +403,52 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 }
                 if (end_path) finish_path();
             }
+        }
 
-            // ---- job hand-out: one atomic per wave for all lanes that ran dry -----------------
-            bool got_job = false;
-            const bool want_job = need_path;
-            const unsigned long long m_job = __ballot(want_job);
-            if (want_job) {
+        // ---- job hand-out: one atomic per wave for all lanes that ran dry -----------------
+        // kQueues job queues, queue g = the g-th horizontal stripe of tiles; a wave starts on the queue of its
+        // workgroup's XCD group (blockIdx % 8: which blocks share an XCD and its L2, not which XCD - a speed matter
+        // only) and moves on to the next one when its queue is exhausted, so neighbouring tiles run on one L2.
+        bool got_job = false;
+        const bool want_job = want_post && need_path;
+        const unsigned long long m_job = __ballot(want_job);
+        if (m_job != 0ull) {
+            const bool open = q_done < (uint32_t)kQueues;
+            const uint32_t n_want = (uint32_t)__popcll(m_job);
+            const uint32_t tile_lo = (uint32_t)(((unsigned long long)n_tiles * q_cur) / kQueues);
+            const uint32_t tile_hi = (uint32_t)(((unsigned long long)n_tiles * (q_cur + 1u)) / kQueues);
+            const uint32_t q_size = (tile_hi - tile_lo) * 64u * n_iterations;
+            uint32_t base = 0;
+            if (open) {
                 const int leader = __ffsll((long long)m_job) - 1;
+                if ((int)(tid & 63u) == leader) base = atomicAdd(&job_counter[q_cur], n_want);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, leader));
+            }
+            if (want_job) {
                 const uint32_t rank = __popcll(m_job & ((1ull << (tid & 63u)) - 1ull));
-                uint32_t base = 0;
-                if ((int)(tid & 63u) == leader) base = atomicAdd(job_counter, (uint32_t)__popcll(m_job));
-                base = __shfl(base, leader);
                 const uint32_t job = base + rank;
-                if (job >= n_jobs) {
-                    alive = false;
-                } else {
-                    // iteration-major; inside an iteration 8x8 tiles in row-major order
-                    const uint32_t it_local = job / jobs_per_iteration;
-                    const uint32_t rem = job - it_local * jobs_per_iteration;
-                    const uint32_t tile = rem >> 6, in_tile = rem & 63u;
+                if (!open) {
+                    alive = false;  // every queue has been seen empty
+                } else if (job < q_size) {
+                    // tile-major: the iterations of one 8x8 tile are consecutive jobs, so the waves that take them (at
+                    // about the same time) send their camera rays and first shadow rays through the same part of the tree
+                    const uint32_t unit = job >> 6, in_tile = job & 63u;
+                    const uint32_t tile_in_q = unit / n_iterations;
+                    const uint32_t it_local = unit - tile_in_q * n_iterations;
+                    const uint32_t tile = tile_lo + tile_in_q;
                     gx = (tile % tiles_x) * 8u + (in_tile & 7u);
                     gy = (tile / tiles_x) * 8u + (in_tile >> 3);
                     it = first_iteration + it_local;
                     got_job = gx < sc.width && gy < sc.height;  // edge tiles: pixel outside the image, ask again
-                }
+                }  // else: the queue ran out under this wave; the lane asks again in the next pass
             }
+            if (open && base + n_want > q_size) {  // wave-uniform: this queue is (now) exhausted
+                q_cur = (q_cur + 1u) % (uint32_t)kQueues;
+                q_done++;
+            }
+        }
 
+        if (want_post) {
             // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
             if (got_job) {
                 seed = lcg_seed(gx, gy, sc.width, sc.height, it);
@@ -577,7 +603,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         return PTMI_ERR_INVALID_ARGUMENT;
     }
     const uint32_t n_jobs = (uint32_t)jobs64;
-    hipError_t e = hipMemsetAsync(job_counter, 0, sizeof(uint32_t), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(job_counter, 0, ptmi_dev::kQueues * sizeof(uint32_t), (hipStream_t)stream);
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
         if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
