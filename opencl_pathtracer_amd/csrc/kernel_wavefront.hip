@@ -256,20 +256,23 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 if (pending || want_inner) {
                     // nodes and triangles live in one array of 64-byte records (nodes == tris): scalar base + 32-bit
                     // byte offset while the array is below 4 GB (the shift drops a node reference's flag bits)
-                    float4 a, b, c, d;
+                    // Every lane loads the two quads a triangle lane can reject with (see tri_test); node lanes load
+                    // the other two as well, triangle lanes only if the distance tests pass.
+                    const float4* rec;
                     if (!sc.wide_records) {
                         const uint32_t off = (is_tri ? tri_i : cur) << 6;
-                        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + off);
-                        a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3];
+                        rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sc.tris) + off);
                     } else {
-                        const float4* rec = reinterpret_cast<const float4*>(&sc.tris[is_tri ? tri_i : (cur & REF_INDEX_MASK_INNER)]);
-                        a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3];
+                        rec = reinterpret_cast<const float4*>(&sc.tris[is_tri ? tri_i : (cur & REF_INDEX_MASK_INNER)]);
                     }
+                    constexpr int kE1 = PRE ? 1 : 3, kL0 = PRE ? 2 : 1, kL1 = PRE ? 3 : 2;
+                    const float4 e0 = rec[0], e1 = rec[kE1];
                     bool need_pop = false;
                     if (is_tri) {
                         // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
                         p_tri++;
-                        tri_test<PRE>(a, b, c, d, r, limit, [&](const V4& q, float s, float t, bool front, float nsd) {
+                        tri_test<PRE>(e0, e1, [&](float4& l0, float4& l1) { l0 = rec[kL0]; l1 = rec[kL1]; }, r, limit,
+                                      [&](const V4& q, float s, float t, bool front, float nsd) {
                             limit = nsd;
                             if (!shadow) {  // closest hit so far: the record path logic will shade from
                                 hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
@@ -288,6 +291,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         tri_i++;
                     } else {
                         // ---- one inner-node step (:660-697)
+                        const float4 l0 = rec[kL0], l1 = rec[kL1];
+                        const float4 a = e0, b = PRE ? e1 : l0, c = PRE ? l0 : l1, d = PRE ? l1 : e1;
                         const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
                         const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
                         const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
