@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--kernel", choices=["wavefront", "megakernel"], default="wavefront")
     ap.add_argument("--scheduler-stats", action="store_true", help="also report wave-scheduler statistics (costs ~1 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-histograms", action="store_true",
+                    help="skip the reference's three per-path statistics atomics (FullKernel.cl:1319-1331); default: keep them")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo is a rehearsal of the N>1 control flow on a one-GPU box "
                          "(all ranks share GPU 0, accumulators are reduced through host memory)")
@@ -83,7 +85,7 @@ def main():
     t_scene = time.time() - t0
 
     be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=local_rank,
-                                    flags=FLAG_NO_HISTOGRAMS | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0)
+                                    flags=(FLAG_NO_HISTOGRAMS if args.no_histograms else 0) | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0)
                                     | (FLAG_SCHEDULER_STATS if args.scheduler_stats else 0))
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)

@@ -520,7 +520,7 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
             ctx->stage_iterations = 0;
             const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
             void* p = nullptr;
-            HIP_TRY(ctx, hipMalloc(&p, want * npix * 16));
+            HIP_TRY(ctx, hipMalloc(&p, want * npix * 20));  // float4 radiance + one statistics word per path
             ctx->d_stage = (float*)p;
             ctx->stage_iterations = want;
         }
@@ -531,6 +531,12 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
     if (megakernel) {
         rc = launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err);
     } else {
+        // histograms: staged per path and counted after the launch, unless there is no staging (RANDOM sampler),
+        // no histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
+        uint32_t* stage_stats = nullptr;
+        if (ctx->d_stage && ctx->ds.hist_depths && ctx->cfg.ray_max_depth < 64)
+            stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_stage) +
+                                                      ctx->stage_iterations * (size_t)ctx->cfg.image_width * ctx->cfg.image_height * 16);
         // one launch per chunk of iterations; chunks run back to back on the stream, in order
         for (uint32_t done = 0; done < n_iterations && rc == PTMI_OK;) {
             // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
@@ -538,7 +544,7 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
             const uint32_t n = n_iterations - done < cap ? n_iterations - done : cap;
             rc = launch_render_wavefront(ctx->ds, ctx->d_scene, first_iteration + done, n, ctx->d_job_counter, ctx->resident_blocks,
                                          ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0,
-                                         ctx->d_stage, ctx->stream, &err);
+                                         ctx->d_stage, stage_stats, ctx->stream, &err);
             done += n;
         }
     }

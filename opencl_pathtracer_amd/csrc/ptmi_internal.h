@@ -140,7 +140,8 @@ int wavefront_resident_blocks(int device, uint32_t stack_levels);
 // scene_in_device_memory = a device copy of `sc` (the kernel takes only the hot fields by value)
 int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
                             uint32_t n_iterations, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
-                            bool scheduler_stats, float* stage, void* stream, std::string* err);
+                            bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err);
+// stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself)
 
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
 constexpr uint32_t kMaxIterationsPerLaunch = 16;

@@ -196,6 +196,15 @@ def test_axis_aligned_rays_and_unordered_boxes_take_the_literal_box_test(kernel,
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
 
 
+def test_deep_paths_keep_the_direct_statistics_atomics(scene_factory):
+    """Path depths that do not fit the staged statistics word (>= 64) fall back to the reference's three atomics."""
+    sc = scene_factory("matmix", 48, 32)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 48, 32, 70, 2)
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 48, 32, 70, 2)
+    assert counters == totals and np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+
+
 def test_wide_record_addresses(scene_factory, monkeypatch):
     """Record arrays of 4 GB or more need 64-bit byte offsets; the switch forces that path on a small scene."""
     monkeypatch.setenv("PTMI_WIDE_RECORDS", "1")
