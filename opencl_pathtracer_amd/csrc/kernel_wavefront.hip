@@ -6,12 +6,15 @@
 // partial exec masks.  Here instead:
 //
 //  * The grid is PERSISTENT: as many workgroups as the chip holds, alive for the whole launch.  Work is
-//    a queue of jobs, job = ONE PATH (pixel, iteration), handed out 8x8-tile-wise by one atomic per wave
-//    whenever some of its lanes run dry (`dequeue` in MI355X_MICROARCH.md: the cheapest cross-CU
-//    primitive).  A finished path stores its radiance (16 B) into a staging array [iteration][pixel]; a
-//    trivial follow-up kernel adds the staged values to the framebuffer pixel by pixel IN ITERATION ORDER,
-//    so the float sums are the reference's, bit for bit, without atomics.  (Jobs of one pixel x all
-//    iterations kept the sum in registers but left a tail of one whole job per lane: -12 % at 1080p.)
+//    jobs, job = ONE PATH (pixel, iteration), in 8 queues (8 stripes of 8x8 tiles, tile-major: the iterations
+//    of a tile are consecutive jobs); a wave starts on the queue of its workgroup's XCD group, so neighbouring
+//    tiles run at the same time on one L2, and takes jobs for all lanes that ran dry with one atomic.
+//    A finished path stores its radiance (16 B) and its three statistics bins (4 B) into staging arrays
+//    [iteration][pixel]; two trivial follow-up kernels add the staged radiances to the framebuffer pixel by
+//    pixel IN ITERATION ORDER (the float sums are the reference's, bit for bit, without atomics) and count
+//    the histograms in LDS.  (Jobs of one pixel x all iterations kept the sum in registers but left a tail of
+//    one whole job per lane: -12 % at 1080p.  Three global atomics per path for the histograms: -79 % on the
+//    Cornell box.)
 //  * Every lane is a small STATE MACHINE over the same three step kinds:
 //        I  one inner-node step  (load one 64-byte DNode, two slab tests, push/pop on the LDS stack)
 //        T  one triangle test    (load one 64-byte DTri)
@@ -19,16 +22,20 @@
 //                                 scatter, finish the path, start the next iteration or fetch a new job)
 //    A camera segment and a shadow ray are the same I/T steps with another `limit` and exit rule, so lanes
 //    in either phase, of any bounce, of any pixel, run together.
-//  * Per loop trip the WAVE picks one kind by __ballot / popcount: P when enough lanes wait for it (or
-//    nothing else can run), otherwise the kind more lanes want.  Lanes of the other kinds sit out that
-//    trip; none is ever more than a few trips from running because waiters accumulate.
+//  * LOOP NEST: traversal trips in an inner loop - in a trip EVERY traversing lane takes one step, I or T,
+//    both fed by the same record loads - and a path-logic pass in the outer loop when the lanes waiting for
+//    it have waited long enough (wait debt) or nothing can traverse.
 //  * Per ray the visit sequence is exactly the reference's (near child first, far child pushed, leaf
 //    triangles in index order, limit updated between tests, FullKernel.cl:620-702): only WHEN a lane
 //    takes its next step changes, never WHICH step it takes.  Results are bit-identical to the
 //    one-path-per-lane kernel (kernels.hip) and to the CPU checker.
 //
-// Exit: a lane dies when the queue is empty and its pixel is flushed; a wave leaves the loop when no lane
-// has work of any kind (every path is bounded by the ray depth, every traversal by the finite tree).
+// Exit: a lane dies when it has seen every queue empty; a wave leaves the outer loop when no lane is alive
+// (every path is bounded by the ray depth, every traversal by the finite tree, and a pass or trip only runs
+// with at least one lane that wants it).
+//
+// The kernel's limits, measured: DESIGN.md 5 "What binds" (VALU issue, L1 access rate and L1-miss line rate
+// within 20 % of each other).  tools/isa_trip.sh prints the instruction mix of the traversal loop.
 #include <hip/hip_runtime.h>
 
 #include "ptmi_device.hpp"
