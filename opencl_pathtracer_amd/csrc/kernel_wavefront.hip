@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         sp = below < stack_floor ? stack_floor : below;
                     }
                 }
-                    survey();
+                survey();
                 if ((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0)) break;
             }
         }
