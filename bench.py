@@ -104,6 +104,12 @@ def main():
     torch.cuda.set_stream(stream)
     for s in range(args.warmup):
         step(s)
+    if world > 1 and args.backend == "nccl" and args.warmup > 0:
+        # warm the collective too (RCCL sets up its channels for a message size on first use): same size, same
+        # stream, scratch data - the accumulators are only reduced once, inside the timed region
+        scratch = torch.zeros_like(fb.buffer)
+        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        del scratch
     torch.cuda.synchronize(device)
     be.kernel_time()  # drop warm-up launches
     c0 = be.counters()
