@@ -282,7 +282,7 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         d.hi1[0] = b1.p_max.x; d.hi1[1] = b1.p_max.y; d.hi1[2] = b1.p_max.z;
         d.lo2[0] = b2.p_min.x; d.lo2[1] = b2.p_min.y; d.lo2[2] = b2.p_min.z;
         d.hi2[0] = b2.p_max.x; d.hi2[1] = b2.p_max.y; d.hi2[2] = b2.p_max.z;
-        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.axis_bit = 1u << n.cut_axis;  // inner children: index patched in when they are emitted
+        d.ref1 = r1; d.ref2 = r2; d.axis = n.cut_axis; d.pad = 0;  // inner children: index patched in when they are emitted
         // the short slab test (box_hit_ordered) needs finite, ordered boxes; anything else keeps the literal form
         for (int k = 0; k < 3; k++) {
             if (!(r1 & REF_EMPTY) && !(std::isfinite(d.lo1[k]) && std::isfinite(d.hi1[k]) && d.lo1[k] <= d.hi1[k])) out.boxes_ordered = false;

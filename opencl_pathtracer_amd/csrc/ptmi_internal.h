@@ -48,8 +48,8 @@ struct DNode {
     float lo1[3], hi1[3];  // son1Id's trianglesAABB pMin/pMax xyz
     float lo2[3], hi2[3];  // son2Id's
     uint32_t ref1, ref2;
-    uint32_t axis;      // cutAxis
-    uint32_t axis_bit;  // 1 << cutAxis
+    uint32_t axis;  // cutAxis
+    uint32_t pad;
 };
 static_assert(sizeof(DNode) == 64, "DNode");
 
