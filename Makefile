@@ -8,7 +8,7 @@ CSRC       := opencl_pathtracer_amd/csrc
 LIBDIR     := opencl_pathtracer_amd/lib
 # -ffp-contract=off: the numerics contract forbids fused multiply-add
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-LIB_SRCS   := $(CSRC)/kernels.hip $(CSRC)/kernel_wavefront.hip $(CSRC)/ptmi_api.cpp $(CSRC)/bvh_build.cpp
+LIB_SRCS   := $(CSRC)/kernels.hip $(CSRC)/kernel_wavefront.hip $(CSRC)/display.hip $(CSRC)/ptmi_api.cpp $(CSRC)/bvh_build.cpp
 LIB_HDRS   := $(wildcard include/*.h) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp)
 
 .PHONY: all lib shim oracle ref clean resources

@@ -133,6 +133,13 @@ int ptmi_synchronize(ptmi_ctx* ctx);
  * count.  Either pointer may be NULL.  Synchronises first. */
 int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb);
 
+/* What the reference's viewer does with those two buffers after every image - ConvertRGBAToBMPBuffer,
+ * Alone/PathTracer_bitmap.cpp:237-286, called from Alone/PathTracer_Dialog.cpp:161-185 - done on the device:
+ * 24-bit B,G,R scanlines, image row 0 first, each `row_stride` bytes long ((3*W + 3) & ~3, the BMP padding, zero
+ * filled), pixel = (int) min(sum * 255.f / n, 255.f); 3 bytes per pixel cross the bus instead of 20.
+ * `bgr` holds H * row_stride bytes.  Synchronises first. */
+int ptmi_read_display(ptmi_ctx* ctx, uint8_t* bgr, uint32_t row_stride);
+
 /* Replaces the three statistic reads after the loop (OpenCL.cpp:110-112):
  * ray_depths[ray_max_depth+1], ray_intersected_bbx[5000], ray_intersected_tri[5000].
  * Any pointer may be NULL. */

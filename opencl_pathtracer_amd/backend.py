@@ -81,7 +81,7 @@ FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront ker
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_last_error",
                "ptmi_abi_version", "ptmi_device_count", "ptmi_bvh_create"]
@@ -105,6 +105,7 @@ def load_library():
     lib.ptmi_render.argtypes = [vp, u32, u32]
     lib.ptmi_synchronize.argtypes = [vp]
     lib.ptmi_read_image.argtypes = [vp, vp, vp]
+    lib.ptmi_read_display.argtypes = [vp, vp, u32]
     lib.ptmi_read_statistics.argtypes = [vp, vp, vp, vp]
     lib.ptmi_clear.argtypes = [vp]
     lib.ptmi_release.argtypes = [vp]
@@ -217,6 +218,15 @@ class Backend:
         count = np.empty((h, w), np.float32)
         self._check(self._lib.ptmi_read_image(self._ctx, _ptr(color), _ptr(count)))
         return color, count
+
+    def read_display(self):
+        """Padded B,G,R scanlines uint8[H, (3W+3)&~3] quantised on the device as the reference's viewer does on the
+        host (ConvertRGBAToBMPBuffer, Alone/PathTracer_bitmap.cpp:237-286)."""
+        h, w = self.cfg.image_height, self.cfg.image_width
+        stride = (3 * w + 3) & ~3
+        out = np.empty((h, stride), np.uint8)
+        self._check(self._lib.ptmi_read_display(self._ctx, _ptr(out), stride))
+        return out
 
     def read_statistics(self):
         """(rayDepths[D+1], rayIntersectedBBx[5000], rayIntersectedTri[5000]), OpenCL.cpp:110-112."""

@@ -1,0 +1,65 @@
+// display.hip - accumulators -> displayed pixels on the device.
+//
+// What the reference shows and saves after every image is produced on the host from the two float buffers it has just
+// read back (41.5 MB at 1080p, PathTracer_OpenCL.cpp:97-98): ConvertRGBAToBMPBuffer, Alone/PathTracer_bitmap.cpp:237-286.
+// The same quantisation here, on the device, so that a viewer only has to fetch 3 bytes per pixel (6.2 MB at 1080p):
+//   pixel = (int) min(sum * 255.f / n, 255.f) per channel, `min` being the Windows macro a < b ? a : b (a NaN from 0/0
+//   on a never-sampled pixel shows as 255); a negative red sum marks the pixel pure red (:262 tests .x three times);
+//   bytes in B, G, R order, rows padded to a multiple of 4 and zero-filled, image row 0 first.
+#include <hip/hip_runtime.h>
+
+#include "ptmi_internal.h"
+
+namespace ptmi_dev {
+
+__device__ __forceinline__ uint32_t display_channel(float sum, float n)
+{
+    const float v = sum * 255.f / n;  // IEEE multiply, then IEEE divide (no contraction, no reciprocal)
+    const float m = v < 255.f ? v : 255.f;
+    return (uint32_t)(int)m & 0xFFu;  // (BYTE)(int)
+}
+
+__global__ void __launch_bounds__(256) display_bgr_kernel(const float* __restrict__ image_color, const float* __restrict__ image_ray_nb,
+                                                          uint8_t* __restrict__ out, const uint32_t width, const uint32_t height,
+                                                          const uint32_t row_stride)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (y >= height) return;
+    uint8_t* row = out + (size_t)y * row_stride;
+    if (x < width) {
+        const size_t p = (size_t)y * width + x;
+        const float4 c = reinterpret_cast<const float4*>(image_color)[p];
+        const float n = image_ray_nb[p];
+        uint32_t r = 255u, g = 0u, b = 0u;
+        if (!(c.x < 0)) {
+            r = display_channel(c.x, n);
+            g = display_channel(c.y, n);
+            b = display_channel(c.z, n);
+        }
+        row[3 * x + 0] = (uint8_t)b;
+        row[3 * x + 1] = (uint8_t)g;
+        row[3 * x + 2] = (uint8_t)r;
+    }
+    // padding bytes of the scanline (memset 0 in the reference)
+    if (x < row_stride - 3u * width) row[3u * width + x] = 0;
+}
+
+}  // namespace ptmi_dev
+
+namespace ptmi_internal {
+
+int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint8_t* out, uint32_t width, uint32_t height,
+                       uint32_t row_stride, void* stream, std::string* err)
+{
+    const dim3 grid((width + 255u) / 256u, height), block(256);
+    hipLaunchKernelGGL(ptmi_dev::display_bgr_kernel, grid, block, 0, (hipStream_t)stream, image_color, image_ray_nb, out, width,
+                       height, row_stride);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("display_bgr_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    return PTMI_OK;
+}
+
+}  // namespace ptmi_internal

@@ -51,6 +51,8 @@ struct ptmi_ctx {
     uint32_t* d_hist = nullptr;  // depths | bbx | tri
     unsigned long long* d_counters = nullptr;
     uint32_t* d_job_counter = nullptr;
+    uint8_t* d_display = nullptr;    // B,G,R scanlines of ptmi_read_display
+    size_t display_bytes = 0;
     float* d_stage = nullptr;        // staged radiances [iteration][pixel] float4 of the launch in flight
     size_t stage_iterations = 0;
     int resident_blocks = 0;
@@ -92,6 +94,9 @@ void free_scene_memory(ptmi_ctx* ctx)
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     ctx->d_stage = nullptr;
     ctx->stage_iterations = 0;
+    if (ctx->d_display) (void)hipFree(ctx->d_display);
+    ctx->d_display = nullptr;
+    ctx->display_bytes = 0;
     ctx->accum_bound = false;
     ctx->have_scene = false;
 }
@@ -570,6 +575,32 @@ int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb)
     const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
     if (image_color) HIP_TRY(ctx, hipMemcpyAsync(image_color, ctx->ds.image_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (image_ray_nb) HIP_TRY(ctx, hipMemcpyAsync(image_ray_nb, ctx->ds.image_ray_nb, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PTMI_OK;
+}
+
+int ptmi_read_display(ptmi_ctx* ctx, uint8_t* bgr, uint32_t row_stride)
+{
+    if (!ctx || !bgr) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_display before ptmi_initialize_memory");
+    const uint32_t w = ctx->cfg.image_width, h = ctx->cfg.image_height;
+    if (row_stride < 3u * w || row_stride > 3u * w + 3u)
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "row_stride must be 3*W plus 0..3 padding bytes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)h * row_stride;
+    if (bytes > ctx->display_bytes) {
+        if (ctx->d_display) (void)hipFree(ctx->d_display);
+        ctx->d_display = nullptr;
+        ctx->display_bytes = 0;
+        void* p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, bytes));
+        ctx->d_display = (uint8_t*)p;
+        ctx->display_bytes = bytes;
+    }
+    std::string err;
+    if (int rc = launch_display_bgr(ctx->ds.image_color, ctx->ds.image_ray_nb, ctx->d_display, w, h, row_stride, ctx->stream, &err))
+        return fail(ctx, rc, err);
+    HIP_TRY(ctx, hipMemcpyAsync(bgr, ctx->d_display, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PTMI_OK;
 }

@@ -143,6 +143,10 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
                             bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err);
 // stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself)
 
+// display.hip: accumulators -> padded B,G,R scanlines (the reference's ConvertRGBAToBMPBuffer), on the device
+int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint8_t* out, uint32_t width, uint32_t height,
+                       uint32_t row_stride, void* stream, std::string* err);
+
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
 constexpr uint32_t kMaxIterationsPerLaunch = 16;
 

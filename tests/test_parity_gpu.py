@@ -205,6 +205,38 @@ def test_deep_paths_keep_the_direct_statistics_atomics(scene_factory):
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
 
 
+def test_display_scanlines_equal_the_host_quantisation(scene_factory):
+    """ptmi_read_display (device) == ConvertRGBAToBMPBuffer restated on the host (output.to_bmp_buffer), byte for byte,
+    including the padding of a width that is not a multiple of 4, never-sampled pixels (0/0 -> 255) and the
+    negative-red marker."""
+    import torch
+    from opencl_pathtracer_amd import output
+    torch.cuda.set_device(0)  # (torch wants to be the first HIP user of the process)
+    w, h = 50, 37  # 150 bytes per row -> 2 padding bytes
+    sc = scene_factory("matmix", w, h)
+    be = Backend().setup_context(w, h, 6, sc.lightsSize, S.JITTERED)
+    be.initialize_memory(sc)
+    shown = be.read_display()                      # nothing rendered yet: 0/0 everywhere
+    assert shown.shape == (h, 152) and (shown[:, :150] == 255).all() and (shown[:, 150:] == 0).all()
+    be.render(0, 5)
+    color, count = be.read_image()
+    expect, stride = output.to_bmp_buffer(color, count)
+    assert stride == 152
+    assert be.read_display().tobytes() == expect
+    be.release()
+    # the negative-red marker and saturation, on caller-made accumulators
+    rs = np.random.RandomState(2)
+    c = (rs.uniform(-0.5, 3.0, (h, w, 4))).astype(np.float32)
+    n = rs.randint(0, 3, (h, w)).astype(np.float32)
+    expect, _ = output.to_bmp_buffer(c, n)
+    be = Backend().setup_context(w, h, 6, sc.lightsSize, S.JITTERED)
+    be.initialize_memory(sc)
+    tc, tn = torch.from_numpy(c).cuda(), torch.from_numpy(n).cuda()
+    be.bind_accumulators(tc.data_ptr(), tn.data_ptr())
+    assert be.read_display().tobytes() == expect
+    be.release()
+
+
 def test_wide_record_addresses(scene_factory, monkeypatch):
     """Record arrays of 4 GB or more need 64-bit byte offsets; the switch forces that path on a small scene."""
     monkeypatch.setenv("PTMI_WIDE_RECORDS", "1")
