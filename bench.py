@@ -178,7 +178,10 @@ def main():
                          "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
                          "box_tests_per_path": delta["box_tests"] / max(delta["paths"], 1),
-                         "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1)},
+                         "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1),
+                         "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; a fraction above 1 means the record "
+                                 "stream is served by L2 + Infinity Cache (see traffic = measured HBM bytes per launch), "
+                                 "DESIGN.md 5 'What binds'"},
         }
         if sched["trips_node"]:
             out["wave_scheduler"] = {k: round(sched["lanes_" + k] / (64.0 * sched["trips_" + k]), 3) if sched["trips_" + k] else None
