@@ -133,6 +133,10 @@ int ptmi_synchronize(ptmi_ctx* ctx);
  * count.  Either pointer may be NULL.  Synchronises first. */
 int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb);
 
+/* The inverse of ptmi_read_image: load the accumulators (e.g. to resume a render saved earlier, or to accumulate on top of
+ * another device's partial result).  Either pointer may be NULL (left as is).  Synchronises first. */
+int ptmi_write_image(ptmi_ctx* ctx, const float* image_color, const float* image_ray_nb);
+
 /* What the reference's viewer does with those two buffers after every image - ConvertRGBAToBMPBuffer,
  * Alone/PathTracer_bitmap.cpp:237-286, called from Alone/PathTracer_Dialog.cpp:161-185 - done on the device:
  * 24-bit B,G,R scanlines, image row 0 first, each `row_stride` bytes long ((3*W + 3) & ~3, the BMP padding, zero
@@ -167,6 +171,13 @@ int ptmi_set_stream(ptmi_ctx* ctx, void* hip_stream);
 /* Device pointers of the accumulators (float[4*W*H], float[W*H]) so a caller
  * that owns a collective library can reduce them in place (multi-GPU spp shards). */
 int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_image_color, void** d_image_ray_nb);
+
+/* SUPER_SAMPLING only: the per-pixel variance accumulator global__imageV (float4[W*H]; the sum of squared
+ * deviations the stop criterion reads, FullKernel.cl:1152-1172,1346-1349).  Needed to combine the shards of a multi-GPU
+ * render, where it does not merge by a plain sum (opencl_pathtracer_amd/distributed.py: merge_moments).
+ * PTMI_ERR_STATE without super_sampling. */
+int ptmi_read_variance(ptmi_ctx* ctx, float* image_v);
+int ptmi_device_variance(ptmi_ctx* ctx, void** d_image_v);
 
 /* Adopt caller-allocated device buffers as accumulators (e.g. torch tensors);
  * they are NOT zeroed and NOT freed by the context.  Pass NULLs to go back. */

@@ -81,9 +81,10 @@ FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront ker
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_write_image", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
                "ptmi_kernel_time",
-               "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_last_error",
+               "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
+               "ptmi_device_variance", "ptmi_last_error",
                "ptmi_abi_version", "ptmi_device_count", "ptmi_bvh_create"]
 
 
@@ -106,6 +107,7 @@ def load_library():
     lib.ptmi_synchronize.argtypes = [vp]
     lib.ptmi_read_image.argtypes = [vp, vp, vp]
     lib.ptmi_read_display.argtypes = [vp, vp, u32]
+    lib.ptmi_write_image.argtypes = [vp, vp, vp]
     lib.ptmi_read_statistics.argtypes = [vp, vp, vp, vp]
     lib.ptmi_clear.argtypes = [vp]
     lib.ptmi_release.argtypes = [vp]
@@ -116,6 +118,8 @@ def load_library():
     lib.ptmi_set_stream.argtypes = [vp, vp]
     lib.ptmi_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ptmi_bind_accumulators.argtypes = [vp, vp, vp]
+    lib.ptmi_read_variance.argtypes = [vp, vp]
+    lib.ptmi_device_variance.argtypes = [vp, C.POINTER(vp)]
     lib.ptmi_last_error.argtypes = [vp]
     lib.ptmi_last_error.restype = C.c_char_p
     lib.ptmi_bvh_create.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
@@ -219,6 +223,12 @@ class Backend:
         self._check(self._lib.ptmi_read_image(self._ctx, _ptr(color), _ptr(count)))
         return color, count
 
+    def write_image(self, image_color=None, image_ray_nb=None):
+        """Load the accumulators (resume a saved render); the inverse of read_image."""
+        c = None if image_color is None else np.ascontiguousarray(image_color, np.float32)
+        n = None if image_ray_nb is None else np.ascontiguousarray(image_ray_nb, np.float32)
+        self._check(self._lib.ptmi_write_image(self._ctx, None if c is None else _ptr(c), None if n is None else _ptr(n)))
+
     def read_display(self):
         """Padded B,G,R scanlines uint8[H, (3W+3)&~3] quantised on the device as the reference's viewer does on the
         host (ConvertRGBAToBMPBuffer, Alone/PathTracer_bitmap.cpp:237-286)."""
@@ -259,6 +269,18 @@ class Backend:
         a, b = C.c_void_p(None), C.c_void_p(None)
         self._check(self._lib.ptmi_device_accumulators(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def read_variance(self):
+        """imageV float32[H,W,4] (SUPER_SAMPLING only): per-channel sum of squared deviations, FullKernel.cl:1346-1349."""
+        h, w = self.cfg.image_height, self.cfg.image_width
+        v = np.empty((h, w, 4), np.float32)
+        self._check(self._lib.ptmi_read_variance(self._ctx, _ptr(v)))
+        return v
+
+    def device_variance(self):
+        a = C.c_void_p(None)
+        self._check(self._lib.ptmi_device_variance(self._ctx, C.byref(a)))
+        return a.value
 
     def bind_accumulators(self, d_color, d_count):
         self._check(self._lib.ptmi_bind_accumulators(self._ctx, C.c_void_p(d_color), C.c_void_p(d_count)))

@@ -579,6 +579,18 @@ int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb)
     return PTMI_OK;
 }
 
+int ptmi_write_image(ptmi_ctx* ctx, const float* image_color, const float* image_ray_nb)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_write_image before ptmi_initialize_memory");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+    if (image_color) HIP_TRY(ctx, hipMemcpy(ctx->ds.image_color, image_color, npix * 16, hipMemcpyHostToDevice));
+    if (image_ray_nb) HIP_TRY(ctx, hipMemcpy(ctx->ds.image_ray_nb, image_ray_nb, npix * 4, hipMemcpyHostToDevice));
+    return PTMI_OK;
+}
+
 int ptmi_read_display(ptmi_ctx* ctx, uint8_t* bgr, uint32_t row_stride)
 {
     if (!ctx || !bgr) return PTMI_ERR_INVALID_ARGUMENT;
@@ -663,6 +675,27 @@ int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_color, void** d_count)
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_device_accumulators before ptmi_initialize_memory");
     if (d_color) *d_color = ctx->ds.image_color;
     if (d_count) *d_count = ctx->ds.image_ray_nb;
+    return PTMI_OK;
+}
+
+int ptmi_device_variance(ptmi_ctx* ctx, void** d_image_v)
+{
+    if (!ctx || !d_image_v) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_device_variance before ptmi_initialize_memory");
+    if (!ctx->ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
+    *d_image_v = ctx->ds.image_v;
+    return PTMI_OK;
+}
+
+int ptmi_read_variance(ptmi_ctx* ctx, float* image_v)
+{
+    if (!ctx || !image_v) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_variance before ptmi_initialize_memory");
+    if (!ctx->ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+    HIP_TRY(ctx, hipMemcpyAsync(image_v, ctx->ds.image_v, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PTMI_OK;
 }
 

@@ -59,3 +59,45 @@ def reduce_statistics(depths, bbx, tri, dst=0, group=None, device=None):
     a = t.cpu().numpy()
     nd, nb = len(depths), len(bbx)
     return a[:nd].astype(np.uint64), a[nd:nd + nb].astype(np.uint64), a[nd + nb:].astype(np.uint64)
+
+
+# ---- SUPER_SAMPLING across ranks ---------------------------------------------------------------------------------
+#
+# With -D SUPER_SAMPLING the kernel keeps, per pixel and channel, the count n, the sum S and imageV = the sum of
+# squared deviations M2, updated one sample at a time as M2 += (x - mean_before) * (x - mean_after)
+# (FullKernel.cl:1346-1349, Welford).  S and n of two shards add; M2 does not:
+#       M2 = M2_a + M2_b + (mean_b - mean_a)^2 * n_a * n_b / (n_a + n_b)          (Chan, Golub, LeVeque 1979)
+# A pixel a shard never sampled (n = 0) contributes nothing.  The reference has no multi-device path; this is what
+# makes the variance image of a sharded render the one a single device would have built from the same samples
+# (up to fp32 rounding) - the per-shard stop decisions themselves are each shard's own.
+
+def merge_moments(sum_a, n_a, m2_a, sum_b, n_b, m2_b):
+    """Combine (sum, n, M2) of two disjoint sample sets; tensors of shape [..., C], [...], [..., C] (torch)."""
+    n = n_a + n_b
+    na, nb, nn = n_a.unsqueeze(-1), n_b.unsqueeze(-1), n.unsqueeze(-1)
+    safe = lambda x: torch.where(x > 0, x, torch.ones_like(x))
+    delta = sum_b / safe(nb) - sum_a / safe(na)
+    cross = delta * delta * (na * nb / safe(nn))
+    both = (na > 0) & (nb > 0)
+    m2 = m2_a + m2_b + torch.where(both, cross, torch.zeros_like(cross))
+    return sum_a + sum_b, n, m2
+
+
+def reduce_super_sampling(color, count, variance, dst=0, group=None):
+    """All ranks pass their (imageColor [P,4], imageRayNb [P], imageV [P,4]); rank `dst` gets the merged triple
+    (the others get their own back).  One all_gather of a fused [9*P] buffer, then a pairwise merge in rank order."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return color, count, variance
+    world = dist.get_world_size(group)
+    p = count.numel()
+    mine = torch.cat([color.reshape(-1), count.reshape(-1), variance.reshape(-1)]).contiguous()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    if dist.get_rank(group) != dst:
+        return color, count, variance
+    split = lambda t: (t[:4 * p].view(p, 4), t[4 * p:5 * p], t[5 * p:].view(p, 4))
+    s, n, m2 = split(parts[0])
+    for t in parts[1:]:
+        sb, nb, mb = split(t)
+        s, n, m2 = merge_moments(s, n, m2, sb, nb, mb)
+    return s.reshape(color.shape), n.reshape(count.shape), m2.reshape(variance.shape)

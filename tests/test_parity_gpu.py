@@ -209,9 +209,7 @@ def test_display_scanlines_equal_the_host_quantisation(scene_factory):
     """ptmi_read_display (device) == ConvertRGBAToBMPBuffer restated on the host (output.to_bmp_buffer), byte for byte,
     including the padding of a width that is not a multiple of 4, never-sampled pixels (0/0 -> 255) and the
     negative-red marker."""
-    import torch
     from opencl_pathtracer_amd import output
-    torch.cuda.set_device(0)  # (torch wants to be the first HIP user of the process)
     w, h = 50, 37  # 150 bytes per row -> 2 padding bytes
     sc = scene_factory("matmix", w, h)
     be = Backend().setup_context(w, h, 6, sc.lightsSize, S.JITTERED)
@@ -223,18 +221,22 @@ def test_display_scanlines_equal_the_host_quantisation(scene_factory):
     expect, stride = output.to_bmp_buffer(color, count)
     assert stride == 152
     assert be.read_display().tobytes() == expect
-    be.release()
-    # the negative-red marker and saturation, on caller-made accumulators
+    # the negative-red marker, saturation and never-sampled pixels, on accumulators loaded with ptmi_write_image
     rs = np.random.RandomState(2)
     c = (rs.uniform(-0.5, 3.0, (h, w, 4))).astype(np.float32)
     n = rs.randint(0, 3, (h, w)).astype(np.float32)
     expect, _ = output.to_bmp_buffer(c, n)
-    be = Backend().setup_context(w, h, 6, sc.lightsSize, S.JITTERED)
-    be.initialize_memory(sc)
-    tc, tn = torch.from_numpy(c).cuda(), torch.from_numpy(n).cuda()
-    be.bind_accumulators(tc.data_ptr(), tn.data_ptr())
+    be.write_image(c, n)
+    back_c, back_n = be.read_image()
+    assert np.array_equal(back_c, c) and np.array_equal(back_n, n)
     assert be.read_display().tobytes() == expect
+    # resuming: 3 iterations on top of loaded accumulators == 5 + 3 in one go
+    be.write_image(color, count)
+    be.render(5, 3)
+    r_color, r_count = be.read_image()
     be.release()
+    o_color, o_count, _, _ = O.oracle_render(sc, w, h, 6, 8)
+    assert np.array_equal(r_count, o_count) and np.array_equal(r_color.view(np.uint32), o_color.view(np.uint32))
 
 
 def test_wide_record_addresses(scene_factory, monkeypatch):

