@@ -101,3 +101,48 @@ def reduce_super_sampling(color, count, variance, dst=0, group=None):
         sb, nb, mb = split(t)
         s, n, m2 = merge_moments(s, n, m2, sb, nb, mb)
     return s.reshape(color.shape), n.reshape(count.shape), m2.reshape(variance.shape)
+
+
+# ---- progressive display of a sharded render ---------------------------------------------------------------------
+#
+# The reference shows the image after every iteration (its callback runs between launches, OpenCL.cpp:97-103).  With
+# the iterations spread over ranks the picture so far is the sum of everybody's partial accumulators: every K
+# iterations each rank snapshots its fused buffer (a device-to-device copy on the render stream) and the snapshots are
+# reduced onto `dst` on a SIDE stream, so the integrator keeps running underneath and the accumulators themselves are
+# never touched by a collective before the final reduce.
+
+class ProgressiveDisplay:
+    def __init__(self, accumulators, dst=0, group=None):
+        self.acc, self.dst, self.group = accumulators, dst, group
+        self.snapshot = torch.zeros_like(accumulators.buffer)
+        self.on_gpu = accumulators.buffer.is_cuda
+        self.side = torch.cuda.Stream(accumulators.buffer.device) if self.on_gpu else None
+        self.work = None
+
+    def submit(self):
+        """Snapshot now (ordered after the launches already queued on the current stream), reduce in the background."""
+        self.wait()
+        self.snapshot.copy_(self.acc.buffer, non_blocking=True)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return
+        if self.on_gpu:
+            self.side.wait_stream(torch.cuda.current_stream(self.snapshot.device))
+            with torch.cuda.stream(self.side):
+                self.work = dist.reduce(self.snapshot, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self.work = dist.reduce(self.snapshot, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.on_gpu:
+            self.side.synchronize()
+
+    def images(self):
+        """(imageColor [H,W,4], imageRayNb [H,W]) of the last submitted snapshot; the sum over ranks on `dst`."""
+        self.wait()
+        a = self.acc
+        c = self.snapshot[: 4 * a.npix].view(a.height, a.width, 4).cpu().numpy()
+        n = self.snapshot[4 * a.npix:].view(a.height, a.width).cpu().numpy()
+        return c, n

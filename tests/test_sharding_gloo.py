@@ -132,3 +132,33 @@ def test_two_rank_super_sampling_variance_merge(tmp_path):
     assert np.array_equal(got["n"], np.full(64, 24, np.float32))
     assert np.allclose(got["s"], xs.sum(0), rtol=1e-5)
     assert np.allclose(got["m"], ((xs - xs.mean(0)) ** 2).sum(0), rtol=2e-4, atol=1e-5)
+
+
+def _progressive_worker(rank, world, port, out_path):
+    sys.path[:0] = [ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opencl_pathtracer_amd.distributed import FusedAccumulators, ProgressiveDisplay
+    fb = FusedAccumulators(8, 4, torch.device("cpu"))
+    shown = ProgressiveDisplay(fb, dst=0)
+    pictures = []
+    for step in range(3):  # "render" = every rank adds (rank + 1) to every accumulator entry
+        fb.buffer += float(rank + 1)
+        shown.submit()
+        c, n = shown.images()
+        pictures.append((float(c[0, 0, 0]), float(n[0, 0])))
+    own = float(fb.buffer[0])  # the accumulators themselves were never reduced
+    fb.reduce_to(0)
+    if rank == 0:
+        np.savez(out_path, pictures=np.array(pictures), own=own, final=fb.buffer.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_progressive_display_reduces_snapshots_not_accumulators(tmp_path):
+    out = str(tmp_path / "prog.npz")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_progressive_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got["pictures"].tolist() == [[3.0, 3.0], [6.0, 6.0], [9.0, 9.0]]  # (1 + 2) per step, summed over both ranks
+    assert got["own"] == 3.0 and (got["final"] == 9.0).all()
