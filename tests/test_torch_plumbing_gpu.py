@@ -33,6 +33,13 @@ def test_bound_accumulators_and_external_stream(scene_factory):
     o_color, o_count, _, _ = O.oracle_render(sc, w, h, d, spp)
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
     assert abs(float(total) - float(o_color.astype(np.float64).sum() + o_count.sum())) <= 1e-3 * float(total)
+    # a progressive-display snapshot taken on the render stream equals the accumulators (single process: no collective)
+    from opencl_pathtracer_amd.distributed import ProgressiveDisplay
+    shown = ProgressiveDisplay(fb)
+    with torch.cuda.stream(stream):
+        shown.submit()
+    p_color, p_count = shown.images()
+    assert np.array_equal(p_color, color) and np.array_equal(p_count, count)
     # device_accumulators reports the bound tensor; unbinding goes back to the context's own (zeroed) buffers
     a, b = be.device_accumulators()
     assert a == fb.color.data_ptr() and b == fb.count.data_ptr()
