@@ -10,7 +10,7 @@ float32, one rounding per operation like the host code):
   sorted lexicographically together with their attributes, vertex normals normalised or replaced
   by ``N`` when degenerate.
 * points carry ``w = 1``, directions ``w = 0`` (MayaImporter.h:29-37).
-* lights / materials / "no sky"  <- MayaImporter.cpp:819-850, 852-932, 695-719.
+* lights / materials / "no sky" / cube-map cross  <- MayaImporter.cpp:819-850, 852-932, 695-817.
 
 The generators below build the BASELINE.json workloads (Cornell box, N random triangles)
 and a material/texture/light mix used by the parity tests.  Every scene is a ``Scene``:
@@ -190,6 +190,31 @@ def no_sky(rgba=(0, 0, 0, 0)):
     for i in range(6):
         sky["skyTextures"][i] = (1, 1, 0)
     texels = np.array([rgba], dtype=np.uint8)
+    return sky, texels
+
+
+def sky_from_cross(bgr, first_texel=0):
+    """LoadSkyAndAllocateTextureMemory(loadSky=true), MayaImporter.cpp:720-817: unpack a horizontal-cross cube map
+    (4 x 3 faces: the top face above and the ground face below the second of four side faces) into the six sky
+    textures.  ``bgr`` is uint8[3*fh, 4*fw, 3] in the byte order of the importer's BMP buffer (B, G, R); texels come out
+    as (r, g, b, 255), faces in the order top, four sides left to right, ground, each ``fw*fh`` texels, the first
+    at ``first_texel`` of texturesData.  Returns (sky record, texels uint8[6*fw*fh, 4])."""
+    bgr = np.asarray(bgr, np.uint8)
+    full_h, full_w = bgr.shape[:2]
+    fw, fh = full_w // 4, full_h // 3
+    if fw == 0 or fh == 0:
+        raise ValueError("cross image smaller than 4x3")
+    blocks = [bgr[0:fh, fw:2 * fw]] + [bgr[fh:2 * fh, i * fw:(i + 1) * fw] for i in range(4)] + [bgr[2 * fh:3 * fh, fw:2 * fw]]
+    texels = np.empty((6 * fw * fh, 4), np.uint8)
+    sky = np.zeros((), dtype=S.Sky)
+    sky["cosRotationAngle"] = 1
+    sky["sinRotationAngle"] = 0
+    sky["groundScale"] = 1
+    for i, blk in enumerate(blocks):
+        t = texels[i * fw * fh:(i + 1) * fw * fh]
+        t[:, :3] = blk.reshape(-1, 3)[:, ::-1]  # b,g,r -> r,g,b
+        t[:, 3] = 255
+        sky["skyTextures"][i] = (fw, fh, first_texel + i * fw * fh)
     return sky, texels
 
 

@@ -52,3 +52,23 @@ def test_load_sky_false_and_errors(tmp_path, built):
         f.truncate(1000)
     with pytest.raises(RuntimeError, match="truncated"):
         scene_cache.import_scene(str(tmp_path))
+
+
+def test_sky_from_cross_unpacks_the_six_faces():
+    """MayaImporter.cpp:720-817: top face above, ground face below the second of the four side faces; b,g,r -> r,g,b,255."""
+    from opencl_pathtracer_amd import scenes
+    fw, fh = 3, 2
+    img = np.zeros((3 * fh, 4 * fw, 3), np.uint8)
+    img[0:fh, fw:2 * fw] = (10, 11, 12)                      # top
+    for i in range(4):
+        img[fh:2 * fh, i * fw:(i + 1) * fw] = (20 + i, 30 + i, 40 + i)
+    img[2 * fh:, fw:2 * fw] = (50, 51, 52)                   # ground
+    img[0, 0] = (99, 99, 99)                                 # a corner of the cross that belongs to no face
+    sky, texels = scenes.sky_from_cross(img, first_texel=7)
+    assert texels.shape == (6 * fw * fh, 4) and (texels[:, 3] == 255).all()
+    want = [(12, 11, 10)] + [(40 + i, 30 + i, 20 + i) for i in range(4)] + [(52, 51, 50)]
+    for i in range(6):
+        assert tuple(sky["skyTextures"][i]) == (fw, fh, 7 + i * fw * fh)
+        assert (texels[i * fw * fh:(i + 1) * fw * fh, :3] == want[i]).all()
+    assert sky["cosRotationAngle"] == 1 and sky["sinRotationAngle"] == 0 and sky["groundScale"] == 1
+    assert not (texels[:, :3] == 99).any()
