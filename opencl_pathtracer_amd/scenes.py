@@ -222,6 +222,17 @@ def camera(position, direction, right, up):
     return _f4(position, 1.0), _f4(direction, 0.0), _f4(right, 0.0), _f4(up, 0.0)
 
 
+def camera_from_film(eye, view, up, right, focal_length_mm, aperture_x_inch, aperture_y_inch, maya_axes=False):
+    """SetCam, MayaImporter.cpp:59-101: unit view / up / right directions and film data -> the four camera vectors the
+    kernel takes.  Right and Up are scaled by aperture / focal length (apertures come in inches, the focal length in
+    millimetres) so that the sample offsets of +-0.5 span the film; with ``maya_axes`` the importer's xyz -> zxy
+    permutation (MayaImporter.h:29-37) is applied as it is to everything coming out of Maya."""
+    perm = (lambda v: np.asarray(v, np.float64)[[2, 0, 1]]) if maya_axes else (lambda v: np.asarray(v, np.float64))
+    r = np.asarray(right, np.float64) * (aperture_x_inch * 25.4 / focal_length_mm)
+    u = np.asarray(up, np.float64) * (aperture_y_inch * 25.4 / focal_length_mm)
+    return camera(perm(eye), perm(view), perm(r), perm(u))
+
+
 def _records(items, dtype):
     """Array of struct records with ZEROED padding bytes (np.array(list_of_records, dtype) leaves them undefined,
     and scene files / digests should not depend on heap garbage)."""

@@ -72,3 +72,14 @@ def test_sky_from_cross_unpacks_the_six_faces():
         assert (texels[i * fw * fh:(i + 1) * fw * fh, :3] == want[i]).all()
     assert sky["cosRotationAngle"] == 1 and sky["sinRotationAngle"] == 0 and sky["groundScale"] == 1
     assert not (texels[:, :3] == 99).any()
+
+
+def test_camera_from_film_scales_and_permutes():
+    """SetCam (MayaImporter.cpp:59-101): Right *= 25.4*apertureX/focal, Up *= 25.4*apertureY/focal (doubles), then zxy."""
+    from opencl_pathtracer_amd import scenes
+    pos, d, r, u = scenes.camera_from_film((1, 2, 3), (0, 0, -1), (0, 1, 0), (1, 0, 0), 35.0, 1.417, 0.945, maya_axes=True)
+    assert pos.tolist() == [3, 1, 2, 1] and d.tolist() == [-1, 0, 0, 0]
+    assert np.array_equal(r, np.array([0, np.float32(1.417 * 25.4 / 35.0), 0, 0], np.float32))
+    assert np.array_equal(u, np.array([0, 0, np.float32(0.945 * 25.4 / 35.0), 0], np.float32))
+    pos, d, r, u = scenes.camera_from_film((1, 2, 3), (0, 0, -1), (0, 1, 0), (1, 0, 0), 50.0, 1.0, 1.0)
+    assert pos.tolist() == [1, 2, 3, 1] and r[0] == np.float32(25.4 / 50.0) and u[1] == np.float32(25.4 / 50.0)
