@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--scene", default="tris1m")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -209,7 +209,7 @@ def committed_traffic(args, W, H, D, B):
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads).  Only quoted for the configuration it was
     measured on; None otherwise (bench.py itself cannot read PMC counters)."""
     path = os.path.join(ROOT, "profiles", "r01_wavefront_pmc.json")
-    if not os.path.exists(path) or (args.scene, W, H, D, B, args.kernel) != ("tris1m", 1920, 1080, 10, 8, "wavefront"):
+    if not os.path.exists(path) or (args.scene, W, H, D, B, args.kernel) != ("tris1m", 1920, 1080, 10, 16, "wavefront"):
         return None
     pmc = json.load(open(path))
     return (2.0 * pmc["FETCH_SIZE"]["per_launch_mean"] + pmc["WRITE_SIZE"]["per_launch_mean"]) * 1024.0

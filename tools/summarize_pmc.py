@@ -15,5 +15,5 @@ for name, per_dispatch in acc.items():
     v = list(per_dispatch.values())[1:] or list(per_dispatch.values())  # drop the warm-up launch
     out[name] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
 out["_note"] = ("rocprofv3 --pmc <one group per run> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline (8 spp per launch, 1M-triangle 1080p workload); FETCH_SIZE/WRITE_SIZE in KB")
+                "--no-cpu-baseline (16 spp per launch, 1M-triangle 1080p workload); FETCH_SIZE/WRITE_SIZE in KB")
 print(json.dumps(out, indent=1))
