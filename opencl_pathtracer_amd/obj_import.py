@@ -14,6 +14,7 @@ import os
 import numpy as np
 
 from . import structs as S
+from . import scenes
 from .scenes import material_create, triangle_create, _concat_tris, _records
 
 
@@ -102,3 +103,24 @@ def load_obj(path, axis_permutation=(0, 1, 2)):
     if not parts:
         raise ValueError(f"{path}: no triangles")  # the Maya importer throws on an empty scene too (:39)
     return _concat_tris(parts), _records(mats, S.Material), names
+
+
+def scene_from_obj(path, width, height, axis_permutation=(0, 1, 2), fov_span=0.8):
+    """A renderable Scene around an OBJ mesh: the camera looks at the mesh's bounding box from the -y side (z up, as in
+    the built-in scenes), one point light above and behind the camera, a light-grey sky.  A convenience for
+    examples/render.py - the reference gets all of this from its Maya scene."""
+    tris, mats, _ = load_obj(path, axis_permutation)
+    pts = np.concatenate([tris["S1"][:, :3], tris["S2"][:, :3], tris["S3"][:, :3]])
+    lo, hi = pts.min(0), pts.max(0)
+    centre, size = (lo + hi) / 2, float(np.linalg.norm(hi - lo))
+    eye = centre + np.array([0.0, -1.6 * size, 0.35 * size])
+    view = centre - eye
+    view = view / np.linalg.norm(view)
+    right = np.cross(view, [0.0, 0.0, 1.0])
+    right = right / np.linalg.norm(right)
+    up = np.cross(right, view)
+    pos, d, r, u = scenes.camera(eye, view, right * fov_span, up * (fov_span * height / width))
+    lights = scenes._records([scenes.light_point(eye + np.array([0.4 * size, 0.0, 1.2 * size]), power=6.0 * size * size)],
+                             S.Light)
+    sky, texels = scenes.no_sky((190, 200, 215, 255))
+    return scenes.Scene(tris, lights, mats, np.zeros(0, S.Texture), texels, sky, pos, d, r, u, name=os.path.basename(path))

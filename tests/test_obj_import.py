@@ -62,3 +62,14 @@ def test_empty_obj_is_an_error(tmp_path):
     (tmp_path / "e.obj").write_text("v 0 0 0\n")
     with pytest.raises(ValueError):
         obj_import.load_obj(str(tmp_path / "e.obj"))
+
+
+def test_scene_from_obj_frames_the_mesh(tmp_path, built):
+    """The convenience wrapper used by examples/render.py: camera outside the mesh looking at it, oracle renders hits."""
+    (tmp_path / "cube.obj").write_text(CUBE)
+    (tmp_path / "cube.mtl").write_text(MTL)
+    sc = bvh_create(obj_import.scene_from_obj(str(tmp_path / "cube.obj"), 32, 24))
+    color, count, (dep, _, _), totals = O.oracle_render(sc, 32, 24, 3, 2)
+    assert totals["surface_hits"] > 0 and np.isfinite(color).all() and (count == 2).all()
+    centre = color[8:16, 12:20, :3].mean()
+    assert centre > 0  # the mesh is in the middle of the frame and lit

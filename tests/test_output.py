@@ -1,7 +1,9 @@
 """Display quantisation and BMP bytes as the reference produces them (PathTracer_bitmap.cpp:146-286)."""
+import os
 import struct
 
 import numpy as np
+import pytest
 
 from opencl_pathtracer_amd import output
 
@@ -36,3 +38,23 @@ def test_bmp_file_layout(tmp_path):
     assert raw[54:57] == bytes([63, 127, 255])           # first pixel of accumulator row 0, as B,G,R
     last = 54 + 2 * 16 + 4 * 3
     assert raw[last:last + 3] == bytes([255, 127, 63]) and raw[54 + 15] == 0  # padding byte
+
+
+@pytest.mark.gpu
+def test_example_renderer_writes_the_bmp_the_host_path_would(tmp_path, scene_factory):
+    """examples/render.py: device-side quantisation + header == output.save_bmp of the oracle's accumulators."""
+    import subprocess
+    import sys
+    import oracle_ffi as O
+    from opencl_pathtracer_amd import output
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "cornell.bmp"
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "render.py"), "--scene", "cornell", "--width", "50",
+                        "--height", "38", "--spp", "6", "--depth", "4", "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Msamples/s" in r.stdout
+    sc = scene_factory("cornell", 50, 38)
+    color, count, _, _ = O.oracle_render(sc, 50, 38, 4, 6)
+    want = tmp_path / "want.bmp"
+    output.save_bmp(str(want), color, count)
+    assert out.read_bytes() == want.read_bytes()
