@@ -64,6 +64,10 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #define PTMI_WF_QUEUES 8
 #endif
 constexpr int kQueues = PTMI_WF_QUEUES;  // job queues (image stripes), one per XCD group of workgroups
+#ifndef PTMI_WF_QUEUE_STRIDE
+#define PTMI_WF_QUEUE_STRIDE 64
+#endif
+constexpr int kQueueStride = PTMI_WF_QUEUE_STRIDE;  // dwords between two queue counters (64 = one 256-byte block each)
 constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
@@ -449,7 +453,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             uint32_t base = 0;
             if (open) {
                 const int leader = __ffsll((long long)m_job) - 1;
-                if ((int)(tid & 63u) == leader) base = atomicAdd(&job_counter[q_cur], n_want);
+                if ((int)(tid & 63u) == leader) base = atomicAdd(&job_counter[q_cur * kQueueStride], n_want);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, leader));
             }
             if (want_job) {
@@ -660,7 +664,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         return PTMI_ERR_INVALID_ARGUMENT;
     }
     const uint32_t n_jobs = (uint32_t)jobs64;
-    hipError_t e = hipMemsetAsync(job_counter, 0, ptmi_dev::kQueues * sizeof(uint32_t), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(job_counter, 0, ptmi_dev::kQueues * ptmi_dev::kQueueStride * sizeof(uint32_t), (hipStream_t)stream);
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
         if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
