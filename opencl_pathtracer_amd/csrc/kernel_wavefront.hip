@@ -48,11 +48,13 @@ namespace ptmi_dev {
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #ifndef PTMI_WF_WAIT_DEBT
-// lane-trips of waiting a wave tolerates before it spends a pass on path logic.  Measured on MI355X, one box, final r01
-// kernel (Msamples/s: 1M triangles 1080p / Cornell box 1080p / material mix 4K):
-//   512: 673 / 2715 / 1444    768: 679    1024: 681 / 3003 / 1647    1536: 676 / 3017 / 1677    2048: 666
-// (a fixed threshold of 8 waiting lanes instead of a debt measured 474 / 743 with an earlier build)
-#define PTMI_WF_WAIT_DEBT 1024
+// lane-trips of waiting a wave tolerates before it spends a pass on path logic.  Measured on MI355X, one box per
+// scene, final r01 kernel (Msamples/s: 1M triangles 1080p / Cornell box 1080p d8 / material mix 4K d16):
+//   256: - / 4883 / 1876    384: 733 / - / 1969    512: 740 / 4804 / 1986    768: 742 / 4896 / 1944
+//   1024: 737 / 4845 / 1872    2048: - / 4840 / 1718
+// (a fixed threshold of 8 waiting lanes instead of a debt measured 474 / 743 with an early build; sweeps made while
+// the job-queue counters still shared a cache line favoured 1024+ on the small scenes - that was the atomics)
+#define PTMI_WF_WAIT_DEBT 512
 #endif
 #ifndef PTMI_WF_MIN_WAVES
 // waves per SIMD the register allocator must fit (5 -> 96 VGPRs, the overflow spills to scratch inside the path-logic
