@@ -43,17 +43,20 @@ __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, con
 
 // Scene_ComputeRadiance, FullKernel.cl:791-891: updates transfer, the ray and
 // isInWater; returns the radiance gathered at this bounce.
-__device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const Hit& hit, const Surface& sf, V4 direct,
-                                      V4& transfer)
+// (split in two so that a caller with several sources of new rays can share ONE copy of the ray set-up, which holds
+// four divisions: scatter_direction = everything up to the outgoing direction `out`, un-normalised as :880 uses it)
+__device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& in_water, const Surface& sf, V4 direct,
+                                                V4& transfer, V4& out_direction)
 {
     V4 N = r.d;
     V4 radiance = v4(0, 0, 0, 0);
     V4 out = r.d;
     const int type = sf.mat.type;
+    bool diffuse = false;  // the outgoing direction is a cosine sample about Ns (drawn once, below, for both users)
     if (type == PTMI_MAT_STANDART) {
         transfer = transfer * sf.color;
         radiance = direct * transfer;
-        out = cosine_sample_hemisphere(seed, sf.Ns);
+        diffuse = true;
         N = sf.Ns;
     } else if (type == PTMI_MAT_GLASS) {
         const float f = fresnel_fraction(1, kNGlass, -dot(r.d, sf.Ns), r.d, sf.Ns, nullptr);
@@ -83,11 +86,20 @@ __device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const H
         if (lcg_random(seed) < f1) {
             out = reflect_about(r.d, sf.Ns);
         } else {
-            out = cosine_sample_hemisphere(seed, sf.Ns);
+            diffuse = true;  // (the Fresnel draw above comes first, as in cl:858-870)
             transfer = transfer * sf.color;
         }
     }
-    out = put_in_same_hemisphere(out, N);
+    if (diffuse) out = cosine_sample_hemisphere(seed, sf.Ns);
+    out_direction = put_in_same_hemisphere(out, N);
+    return radiance;
+}
+
+__device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const Hit& hit, const Surface& sf, V4 direct,
+                                      V4& transfer)
+{
+    V4 out;
+    const V4 radiance = scatter_direction(r, seed, in_water, sf, direct, transfer, out);
     ray_set_direction(r, out);
     r.o = hit.point + out * 0.001f;  // :880 uses the un-normalised direction
     return radiance;
