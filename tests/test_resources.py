@@ -1,0 +1,37 @@
+"""Register / LDS budget of the shipped wavefront-kernel specialisation, read from hipcc's resource remarks (cross-compiles
+without a GPU).  The kernel's speed hangs on 5 waves per SIMD (96 VGPRs) with no scratch traffic inside the traversal
+loop; hipcc's register allocation is fragile, so an innocent-looking edit can cost a wave of occupancy."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_wavefront_kernel_keeps_five_waves_per_simd(tmp_path):
+    csrc = os.path.join(ROOT, "opencl_pathtracer_amd", "csrc")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "--cuda-device-only", "-S",
+           os.path.join(csrc, "kernel_wavefront.hip"), "-o", str(tmp_path / "wf.s"), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # remarks come in blocks: "Function Name: <mangled>" followed by the figures of that function
+    blocks = re.split(r"Function Name: ", r.stderr)[1:]
+    main = [b for b in blocks if b.startswith("_ZN8ptmi_dev23render_wavefront_kernelILb0ELb1ELb0E")]
+    assert len(main) == 1, [b[:60] for b in blocks]
+    figures = {k: int(v) for k, v in re.findall(r"remark: [^\n]*?\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", main[0])}
+    assert figures["VGPRs"] <= 96, figures
+    assert figures["Occupancy"] >= 5, figures
+    # the traversal loop (the only depth-2 loop of every specialisation) must not touch scratch: spills belong to the
+    # path-logic pass
+    depth2, hot_scratch = False, 0
+    for line in open(tmp_path / "wf.s"):
+        if re.match(r"(\.LBB|; %bb\.)", line):
+            depth2 = "Depth=2" in line
+        elif depth2 and "scratch_" in line:
+            hot_scratch += 1
+    assert hot_scratch == 0, f"{hot_scratch} scratch instructions inside a depth-2 loop"
