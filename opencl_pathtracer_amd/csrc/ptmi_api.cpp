@@ -433,7 +433,8 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     HIP_TRY(ctx, hipMalloc(&dc, npix * 16)); ctx->allocations.push_back(dc);
     HIP_TRY(ctx, hipMalloc(&dn, npix * 4));  ctx->allocations.push_back(dn);
     HIP_TRY(ctx, hipMalloc(&dh, hist_words * 4)); ctx->allocations.push_back(dh);
-    HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8 + 256 + 8 * 1024 * 4));  // counters, then the job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart) ctx->allocations.push_back(dk);
+    // counters, then the job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart)
+    HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8 + 256 + 8 * 1024 * 4)); ctx->allocations.push_back(dk);
     void* dsc = nullptr;
     HIP_TRY(ctx, hipMalloc(&dsc, sizeof(DScene))); ctx->allocations.push_back(dsc);
     ctx->d_scene = (DScene*)dsc;
