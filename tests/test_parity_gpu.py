@@ -239,6 +239,29 @@ def test_display_scanlines_equal_the_host_quantisation(scene_factory):
     assert np.array_equal(r_count, o_count) and np.array_equal(r_color.view(np.uint32), o_color.view(np.uint32))
 
 
+def test_reinitialising_and_releasing_returns_the_device_memory(scene_factory):
+    """Every allocation of ptmi_initialize_memory / ptmi_render / ptmi_read_display is released again (a 33 KB block
+    once was not): free device memory after 40 set-up / render / release cycles equals the level after the first."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+    sc = scene_factory("tris20k", 64, 48)
+    levels = []
+    for k in range(40):
+        be = Backend().setup_context(64, 48, 4, sc.lightsSize, S.JITTERED)
+        be.initialize_memory(sc)
+        be.initialize_memory(sc)  # a second scene upload on the same context frees the first
+        be.render(0, 2)
+        be.read_display()
+        be.release()
+        levels.append(free_bytes())
+    assert levels[-1] >= levels[0] - (1 << 20), (levels[0], levels[-1])  # (allocator granularity: well under 40 x 33 KB)
+    assert max(levels[5:]) - min(levels[5:]) <= (2 << 20)
+
+
 def test_wide_record_addresses(scene_factory, monkeypatch):
     """Record arrays of 4 GB or more need 64-bit byte offsets; the switch forces that path on a small scene."""
     monkeypatch.setenv("PTMI_WIDE_RECORDS", "1")
