@@ -13,6 +13,7 @@
 #pragma once
 
 #include <cstdint>
+#include <string>
 
 #include "ptmi_scene.h"
 
@@ -83,5 +84,8 @@ void OpenCL_SetupContext(GlobalVars& globalVars, Sampler sampler);
 
 // Controleur/PathTracer_BVH.h: host-side producer of globalVars.bvh
 void BVH_Create(GlobalVars& globalVars);
+// PathTracer_BVH.h:14: the tree diagnostic the orchestration's printer uses (PathTracer.cpp: PathTracer_PrintBVHCharacteristics)
+void BVH_GetCharacteristics(Node* global__bvh, uint currentNodeId, uint depth, uint& BVHMaxLeafSize, uint& BVHMinLeafSize,
+                            uint& BVHMaxDepth, uint& BVHMinDepth, uint& nNodes, uint& nLeafs, std::string& BVHMaxLeafSizeComments);
 
 }  // namespace PathTracerNS

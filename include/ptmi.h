@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 1
+#define PTMI_ABI_VERSION 2
+#define PTMI_MAX_DEVICES 16       /* devices that can share one render */
+#define PTMI_MAX_SNAPSHOT_SLOTS 16 /* ptmi_snapshot ring */
 
 typedef enum ptmi_status {
     PTMI_OK = 0,
@@ -57,6 +59,14 @@ typedef struct ptmi_config {
     uint32_t super_sampling; /* -D SUPER_SAMPLING (globalVars.superSampling): adaptive sampling, FullKernel.cl:1152-1172,1219-1222;
                                 JITTERED / UNIFORM samplers only (PTMI_ERR_UNSUPPORTED otherwise) */
     uint32_t flags;          /* PTMI_FLAG_* */
+    /* Multi-GPU render (the reference drives devices[0] only, OpenCL.cpp:363-366): n_devices > 1 replicates the scene on
+     * devices[0..n_devices) and spreads the iteration ids of every ptmi_render call over them (device k takes the ids
+     * congruent to k modulo n_devices: the same id set as a single-device render, so the same samples); devices[0] is
+     * the one ptmi_read_image / ptmi_read_snapshot sum the partial accumulators on (peer copies over xGMI + one add
+     * kernel, in device order).  n_devices 0 or 1 = single device `device`.  A device may be listed more than once
+     * (used by the tests on a one-GPU box). */
+    uint32_t n_devices;
+    int32_t devices[PTMI_MAX_DEVICES];
 } ptmi_config;
 
 #define PTMI_FLAG_NO_HISTOGRAMS 1u /* skip the three per-path histogram atomics (FullKernel.cl:1319-1331); totals are still kept */
@@ -130,8 +140,21 @@ int ptmi_synchronize(ptmi_ctx* ctx);
 
 /* Replaces the two blocking clEnqueueReadBuffer of every image (OpenCL.cpp:97-98):
  * image_color = float[4*W*H] sum of radiance, image_ray_nb = float[W*H] sample
- * count.  Either pointer may be NULL.  Synchronises first. */
+ * count.  Either pointer may be NULL.  Waits for everything queued so far.  The bytes cross the bus into pinned
+ * memory: a host buffer handed in a second time is page-locked in place (and stays so until ptmi_release), a
+ * one-off buffer goes through a pinned staging buffer of the context. */
 int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb);
+
+/* The same readback split in two so that the launches of the NEXT images run while image k crosses the bus
+ * (the reference blocks on every image: launch, clFinish, read, callback - OpenCL.cpp:85-103):
+ *   ptmi_snapshot(slot)       queued behind the launches issued so far: a device-side copy of the accumulators
+ *                             (every device of a multi-GPU render) into ring slot `slot` < PTMI_MAX_SNAPSHOT_SLOTS;
+ *   ptmi_read_snapshot(slot)  waits for that copy only (not for launches queued after it), sums the devices'
+ *                             partial images on devices[0], copies the result to the host buffers; with both
+ *                             pointers NULL it only waits until the snapshot has been taken (clFinish of that image).
+ * Loop of a viewer: render(k+1); read_snapshot(k); show; snapshot(k+1) ...  (csrc/PathTracer_HIP.cpp). */
+int ptmi_snapshot(ptmi_ctx* ctx, uint32_t slot);
+int ptmi_read_snapshot(ptmi_ctx* ctx, uint32_t slot, float* image_color, float* image_ray_nb);
 
 /* The inverse of ptmi_read_image: load the accumulators (e.g. to resume a render saved earlier, or to accumulate on top of
  * another device's partial result).  Either pointer may be NULL (left as is).  Synchronises first. */
@@ -165,7 +188,8 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out);
  * last call, measured with HIP events on the context's stream.  Synchronises. */
 int ptmi_kernel_time(ptmi_ctx* ctx, double* total_ms, uint32_t* n_launches);
 
-/* Run on a caller-owned hipStream_t (passed as void*; NULL = context's own). */
+/* Run on a caller-owned hipStream_t (passed as void*; NULL = context's own).  Single-device contexts only, like the
+ * three accumulator entry points below (PTMI_ERR_UNSUPPORTED with n_devices > 1: each device has partial sums). */
 int ptmi_set_stream(ptmi_ctx* ctx, void* hip_stream);
 
 /* Device pointers of the accumulators (float[4*W*H], float[W*H]) so a caller
@@ -177,6 +201,7 @@ int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_image_color, void** d_image
  * render, where it does not merge by a plain sum (opencl_pathtracer_amd/distributed.py: merge_moments).
  * PTMI_ERR_STATE without super_sampling. */
 int ptmi_read_variance(ptmi_ctx* ctx, float* image_v);
+int ptmi_write_variance(ptmi_ctx* ctx, const float* image_v); /* with ptmi_write_image: resume a SUPER_SAMPLING render */
 int ptmi_device_variance(ptmi_ctx* ctx, void** d_image_v);
 
 /* Adopt caller-allocated device buffers as accumulators (e.g. torch tensors);
@@ -189,6 +214,11 @@ const char* ptmi_last_error(const ptmi_ctx* ctx);
 
 int ptmi_abi_version(void);
 int ptmi_device_count(void);
+
+/* Which iteration ids of [first_iteration, first_iteration + n_iterations) device `k` of `n_devices` renders: the ids
+ * congruent to k modulo n_devices = *first_k, *first_k + n_devices, ... (*n_k of them).  Pure arithmetic, no device. */
+void ptmi_device_share(uint32_t first_iteration, uint32_t n_iterations, uint32_t k, uint32_t n_devices, uint32_t* first_k,
+                       uint32_t* n_k);
 
 /* ---- host-side producer of the bvh input -------------------------------- */
 

@@ -43,7 +43,8 @@ class Float4(C.Structure):
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("image_width", C.c_uint32),
                 ("image_height", C.c_uint32), ("ray_max_depth", C.c_uint32), ("lights_size", C.c_uint32),
-                ("sampler", C.c_uint32), ("super_sampling", C.c_uint32), ("flags", C.c_uint32)]
+                ("sampler", C.c_uint32), ("super_sampling", C.c_uint32), ("flags", C.c_uint32),
+                ("n_devices", C.c_uint32), ("devices", C.c_int32 * 16)]
 
 
 class SceneDesc(C.Structure):
@@ -81,11 +82,11 @@ FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront ker
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_write_image", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_write_image", "ptmi_snapshot", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
-               "ptmi_abi_version", "ptmi_device_count", "ptmi_bvh_create"]
+               "ptmi_abi_version", "ptmi_device_count", "ptmi_device_share", "ptmi_bvh_create"]
 
 
 def library_path():
@@ -107,6 +108,9 @@ def load_library():
     lib.ptmi_synchronize.argtypes = [vp]
     lib.ptmi_read_image.argtypes = [vp, vp, vp]
     lib.ptmi_read_display.argtypes = [vp, vp, u32]
+    lib.ptmi_snapshot.argtypes = [vp, u32]
+    lib.ptmi_read_snapshot.argtypes = [vp, u32, vp, vp]
+    lib.ptmi_write_variance.argtypes = [vp, vp]
     lib.ptmi_write_image.argtypes = [vp, vp, vp]
     lib.ptmi_read_statistics.argtypes = [vp, vp, vp, vp]
     lib.ptmi_clear.argtypes = [vp]
@@ -123,6 +127,8 @@ def load_library():
     lib.ptmi_last_error.argtypes = [vp]
     lib.ptmi_last_error.restype = C.c_char_p
     lib.ptmi_bvh_create.argtypes = [vp, u32, vp, C.POINTER(u32), C.POINTER(u32)]
+    lib.ptmi_device_share.argtypes = [u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.ptmi_device_share.restype = None
     _lib = lib
     return lib
 
@@ -134,6 +140,14 @@ def _ptr(a):
 def _f4(v):
     v = np.asarray(v, np.float32)
     return Float4(float(v[0]), float(v[1]), float(v[2]), float(v[3]))
+
+
+def device_share(first_iteration, n_iterations, k, n_devices):
+    """(first_k, n_k): the iteration ids device ``k`` of ``n_devices`` takes from a render call (ids = k mod n_devices)."""
+    lib = load_library()
+    f, n = C.c_uint32(0), C.c_uint32(0)
+    lib.ptmi_device_share(first_iteration, n_iterations, k, n_devices, C.byref(f), C.byref(n))
+    return f.value, n.value
 
 
 def bvh_create(scene):
@@ -172,11 +186,18 @@ class Backend:
 
     # -- OpenCL_SetupContext(globalVars, sampler), OpenCL.cpp:316-402 ---------------------
     def setup_context(self, image_width, image_height, ray_max_depth, lights_size, sampler=S.JITTERED,
-                      super_sampling=False, device=0, flags=0):
+                      super_sampling=False, device=0, flags=0, devices=None):
+        """``devices``: list of HIP ordinals that share every render (spp shards inside the library, summed on the
+        first one); None = the single ``device``, like the reference's devices[0] (OpenCL.cpp:363-366)."""
         if self._ctx:
             self.release()
         cfg = Config(C.sizeof(Config), device, image_width, image_height, ray_max_depth, lights_size, sampler,
                      1 if super_sampling else 0, flags)
+        if devices:
+            cfg.device = devices[0]
+            cfg.n_devices = len(devices)
+            for i, o in enumerate(devices):
+                cfg.devices[i] = o
         ctx = C.c_void_p(None)
         rc = self._lib.ptmi_setup_context(C.byref(ctx), C.byref(cfg))
         if rc:
@@ -221,6 +242,18 @@ class Backend:
         color = np.empty((h, w, 4), np.float32)
         count = np.empty((h, w), np.float32)
         self._check(self._lib.ptmi_read_image(self._ctx, _ptr(color), _ptr(count)))
+        return color, count
+
+    def snapshot(self, slot=0):
+        """Queue a device-side copy of the accumulators behind the launches issued so far (ptmi_snapshot)."""
+        self._check(self._lib.ptmi_snapshot(self._ctx, slot))
+
+    def read_snapshot(self, slot=0, out=None):
+        """Wait for snapshot ``slot`` only and return it; ``out`` = (color, count) arrays to fill (reused buffers are
+        page-locked by the library from their second use on)."""
+        h, w = self.cfg.image_height, self.cfg.image_width
+        color, count = out if out is not None else (np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32))
+        self._check(self._lib.ptmi_read_snapshot(self._ctx, slot, _ptr(color), _ptr(count)))
         return color, count
 
     def write_image(self, image_color=None, image_ray_nb=None):
@@ -277,6 +310,10 @@ class Backend:
         self._check(self._lib.ptmi_read_variance(self._ctx, _ptr(v)))
         return v
 
+    def write_variance(self, image_v):
+        v = np.ascontiguousarray(image_v, np.float32)
+        self._check(self._lib.ptmi_write_variance(self._ctx, _ptr(v)))
+
     def device_variance(self):
         a = C.c_void_p(None)
         self._check(self._lib.ptmi_device_variance(self._ctx, C.byref(a)))
@@ -326,10 +363,10 @@ class Backend:
 
 
 def render_scene(scene, width, height, ray_max_depth, n_iterations, first_iteration=0, sampler=S.JITTERED, device=0,
-                 flags=0, super_sampling=False):
+                 flags=0, super_sampling=False, devices=None):
     """Convenience used by tests/bench: full life cycle for one iteration range."""
     be = Backend().setup_context(width, height, ray_max_depth, scene.lightsSize, sampler, super_sampling=super_sampling,
-                                 device=device, flags=flags)
+                                 device=device, flags=flags, devices=devices)
     try:
         be.initialize_memory(scene)
         be.render(first_iteration, n_iterations)

@@ -15,14 +15,33 @@
 //                                                  the reference (:66-104).
 //   BVH_Create(globalVars)                     -> ptmi_bvh_create (PathTracer_BVH.cpp:12-37): `new Node[2n-1]`,
 //                                                  triangulation reordered in place, bvhSize / bvhMaxDepth set.
+//   BVH_GetCharacteristics(...)                -> the tree statistics walk of PathTracer_BVH.cpp:362-401, which the
+//                                                  orchestration's printer links against (PathTracer.cpp).
+// With these two the file also stands in for Controleur/PathTracer_BVH.cpp; a host that keeps the reference's own
+// builder defines PTMI_SHIM_WITHOUT_BVH.
 //
 // Errors: any failure throws std::runtime_error with the library's message, as every cl error does in the
 // reference (OpenCL_ErrorHandling, OpenCL.cpp:407-486); PathTracer_Main catches std::exception (PathTracer.cpp:99).
 // State: one context per process in a file-scope variable, like the reference's file-scope cl objects
 // (OpenCL.cpp:19-47): one render at a time, released at the end of OpenCL_RunKernel.
 //
-// Environment knobs (optional): PTMI_DEVICE = HIP device ordinal (default 0);
-// PTMI_IMAGES_PER_LAUNCH = iterations rendered per launch and per callback (default 1 = reference behaviour).
+// Where the reference drives devices[0] of its platform (OpenCL.cpp:363-366), this backend spreads the images of a
+// render over EVERY HIP device of the node (iteration ids modulo the device count, inside libptmi) and sums the
+// partial images on the first one before each readback: the caller changes nothing.
+//
+// The render loop keeps the reference's contract - after image k the host buffers hold the sum of images 0..k and the
+// callback runs - but does not idle the GPU while image k crosses the bus and the viewer paints it: the launches of the
+// next PTMI_LOOKAHEAD steps are already queued, and what is read back is a device-side snapshot taken right behind
+// image k's launch (ptmi_snapshot / ptmi_read_snapshot), DMA'd straight into the caller's buffers (page-locked from their
+// second use on).
+//
+// Environment knobs (all optional):
+//   PTMI_DEVICES = "all" (default) or a comma-separated list of HIP ordinals;  PTMI_DEVICE = one ordinal (wins)
+//   PTMI_IMAGES_PER_LAUNCH = images rendered per step and per callback (default 1 = the reference's behaviour)
+//   PTMI_LOOKAHEAD = steps queued ahead of the one being read back (default max(2, devices); 0 = the reference's
+//                    launch / wait / read / callback sequence)
+//   PTMI_LOG = 1 (or globalVars.printLogInfos, the reference's -D LOG_INFO switch, OpenCL.cpp:310): one line per step
+//              on stderr with the iteration range and the three timers
 #ifdef PTMI_USE_REFERENCE_HEADERS
 #include "PathTracer_OpenCL.h"  // the reference's own header (needs CL/cl.h and -fms-extensions for ALIGN)
 #include "PathTracer_BVH.h"
@@ -30,10 +49,12 @@
 #include "pathtracer_backend.hpp"
 #endif
 
+#include <cstdio>
 #include <cstdlib>
 #include <ctime>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "ptmi.h"
 
@@ -42,6 +63,8 @@ namespace PathTracerNS {
 namespace {
 
 ptmi_ctx* g_ctx = nullptr;
+unsigned g_devices = 1;
+bool g_log = false;
 
 [[noreturn]] void fail(const char* where, int code)
 {
@@ -69,7 +92,31 @@ void OpenCL_SetupContext(GlobalVars& globalVars, Sampler sampler)
     }
     ptmi_config cfg{};
     cfg.struct_size = sizeof cfg;
-    cfg.device = (int)env_uint("PTMI_DEVICE", 0);
+    // devices: PTMI_DEVICE = one ordinal; else PTMI_DEVICES = list or "all" (default: every device of the node)
+    std::vector<int> devices;
+    const char* one = std::getenv("PTMI_DEVICE");
+    const char* list = std::getenv("PTMI_DEVICES");
+    if (one && *one) {
+        devices.push_back((int)std::strtol(one, nullptr, 10));
+    } else if (list && *list && std::string(list) != "all") {
+        for (const char* p = list; *p;) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)v);
+            p = (*end == ',') ? end + 1 : end;
+        }
+    } else {
+        const int n = ptmi_device_count();
+        for (int i = 0; i < n && i < PTMI_MAX_DEVICES; i++) devices.push_back(i);
+    }
+    if (devices.empty()) devices.push_back(0);  // no device at all: ptmi_setup_context reports it
+    if (devices.size() > PTMI_MAX_DEVICES) devices.resize(PTMI_MAX_DEVICES);
+    cfg.device = devices[0];
+    cfg.n_devices = (uint32_t)devices.size();
+    for (size_t i = 0; i < devices.size(); i++) cfg.devices[i] = devices[i];
+    g_devices = (unsigned)devices.size();
+    g_log = globalVars.printLogInfos || env_uint("PTMI_LOG", 0) != 0;
     cfg.image_width = globalVars.imageWidth;
     cfg.image_height = globalVars.imageHeight;
     cfg.ray_max_depth = globalVars.rayMaxDepth;
@@ -116,24 +163,41 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
     *memoryTime = 0;
     *displayTime = 0;
     const unsigned batch = env_uint("PTMI_IMAGES_PER_LAUNCH", 1) ? env_uint("PTMI_IMAGES_PER_LAUNCH", 1) : 1;
-    uint imageId = 0;
-    while (imageId < numImagesToRender) {
-        const uint n = numImagesToRender - imageId < batch ? numImagesToRender - imageId : batch;
-        std::clock_t start = std::clock();
-        int rc = ptmi_render(g_ctx, imageId, n);
-        if (!rc) rc = ptmi_synchronize(g_ctx);
+    unsigned lookahead = env_uint("PTMI_LOOKAHEAD", g_devices > 2 ? g_devices : 2);
+    if (lookahead > PTMI_MAX_SNAPSHOT_SLOTS - 2) lookahead = PTMI_MAX_SNAPSHOT_SLOTS - 2;  // one slot is the library's own
+    const unsigned slots = lookahead + 1;
+    const uint steps = (numImagesToRender + batch - 1) / batch;
+    // step s = images [s * batch, min((s + 1) * batch, numImagesToRender)): launch(es) + a snapshot behind them
+    auto enqueue = [&](uint s) {
+        const uint first = s * batch;
+        const uint n = numImagesToRender - first < batch ? numImagesToRender - first : batch;
+        int rc = ptmi_render(g_ctx, first, n);
+        if (!rc) rc = ptmi_snapshot(g_ctx, s % slots);
         if (rc) fail("OpenCL_RunKernel (launch)", rc);
-        *pathTracingTime += std::clock() - start;
+    };
+    uint queued = 0;
+    for (uint s = 0; s < steps; s++) {
+        std::clock_t start = std::clock();
+        while (queued < steps && queued <= s + lookahead) enqueue(queued++);
+        int rc = ptmi_read_snapshot(g_ctx, s % slots, nullptr, nullptr);  // clFinish of image s (OpenCL.cpp:89): later steps keep running
+        if (rc) fail("OpenCL_RunKernel (wait)", rc);
+        const double t_path = (double)(std::clock() - start);
+        *pathTracingTime += t_path;
 
         start = std::clock();
-        rc = ptmi_read_image(g_ctx, reinterpret_cast<float*>(globalVars.imageColor), globalVars.imageRayNb);
+        rc = ptmi_read_snapshot(g_ctx, s % slots, reinterpret_cast<float*>(globalVars.imageColor), globalVars.imageRayNb);
         if (rc) fail("OpenCL_RunKernel (readback)", rc);
-        *memoryTime += std::clock() - start;
+        const double t_mem = (double)(std::clock() - start);
+        *memoryTime += t_mem;
 
         start = std::clock();
         if (UpdateWindowFunc) (*UpdateWindowFunc)();  // return value ignored, as in OpenCL.cpp:103
-        *displayTime += std::clock() - start;
-        imageId += n;
+        const double t_disp = (double)(std::clock() - start);
+        *displayTime += t_disp;
+        if (g_log)
+            std::fprintf(stderr, "[ptmi] images %u..%u of %u on %u device(s): wait %.0f, readback %.0f, display %.0f clock ticks\n", s * batch,
+                         (s + 1) * batch < numImagesToRender ? (s + 1) * batch - 1 : numImagesToRender - 1, numImagesToRender, g_devices,
+                         t_path, t_mem, t_disp);
     }
     const int rc = ptmi_read_statistics(g_ctx, globalVars.rayDepths, globalVars.rayIntersectedBBx, globalVars.rayIntersectedTri);
     if (rc) fail("OpenCL_RunKernel (statistics)", rc);
@@ -141,6 +205,7 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
     g_ctx = nullptr;
 }
 
+#ifndef PTMI_SHIM_WITHOUT_BVH
 void BVH_Create(GlobalVars& globalVars)
 {
     const uint n = globalVars.triangulationSize;
@@ -151,13 +216,44 @@ void BVH_Create(GlobalVars& globalVars)
     uint32_t size = 0, depth = 0;
     const int rc = ptmi_bvh_create(reinterpret_cast<ptmi_triangle*>(globalVars.triangulation), n,
                                    reinterpret_cast<ptmi_node*>(globalVars.bvh), &size, &depth);
-    if (rc) {
+    if (rc) {  // host-only entry point: its message is the library's global one, and a live render context is left alone
         delete[] globalVars.bvh;
         globalVars.bvh = nullptr;
-        fail("BVH_Create", rc);
+        throw std::runtime_error(std::string("BVH_Create failed (") + std::to_string(rc) + "): " + ptmi_last_error(nullptr));
     }
     globalVars.bvhSize = size;
     globalVars.bvhMaxDepth = depth;
 }
+
+// PathTracer_BVH.cpp:362-401.  Kept literally: a leaf that lowers a minimum is not compared against the maximum (else-if),
+// inner nodes count two per visit, and the "comments" out-parameter receives the leaf's stop reason as one character
+// (the reference assigns the enum to a std::string).  Walked with an explicit stack, children in son1, son2 order.
+void BVH_GetCharacteristics(Node* global__bvh, uint currentNodeId, uint depth, uint& BVHMaxLeafSize, uint& BVHMinLeafSize,
+                            uint& BVHMaxDepth, uint& BVHMinDepth, uint& nNodes, uint& nLeafs, std::string& BVHMaxLeafSizeComments)
+{
+    struct Visit { uint id, depth; };
+    std::vector<Visit> todo{{currentNodeId, depth}};
+    while (!todo.empty()) {
+        const Visit v = todo.back();
+        todo.pop_back();
+        const ptmi_node& node = reinterpret_cast<const ptmi_node*>(global__bvh)[v.id];
+        if (node.is_leaf) {
+            nLeafs++;
+            if (v.depth < BVHMinDepth) BVHMinDepth = v.depth;
+            else if (v.depth > BVHMaxDepth) BVHMaxDepth = v.depth;
+            if (node.nb_triangles < BVHMinLeafSize) {
+                BVHMinLeafSize = node.nb_triangles;
+            } else if (node.nb_triangles > BVHMaxLeafSize) {
+                BVHMaxLeafSize = node.nb_triangles;
+                BVHMaxLeafSizeComments = (char)node.comments;
+            }
+            continue;
+        }
+        nNodes += 2;
+        todo.push_back({node.son2_id, v.depth + 1});
+        todo.push_back({node.son1_id, v.depth + 1});
+    }
+}
+#endif  // PTMI_SHIM_WITHOUT_BVH
 
 }  // namespace PathTracerNS

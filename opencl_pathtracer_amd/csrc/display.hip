@@ -44,9 +44,46 @@ __global__ void __launch_bounds__(256) display_bgr_kernel(const float* __restric
     if (x < row_stride - 3u * width) row[3u * width + x] = 0;
 }
 
+// Sum of the partial accumulators of the devices that shared a render, in device order (deterministic; the single-device
+// image differs from it only by the order of these float additions).
+struct ImageParts {
+    const float* p[PTMI_MAX_DEVICES];
+};
+__global__ void __launch_bounds__(256) sum_images_kernel(float* __restrict__ out, const ImageParts parts, const uint32_t n_parts,
+                                                         const size_t n_quads)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_quads) return;
+    float4 s = reinterpret_cast<const float4*>(parts.p[0])[i];
+    for (uint32_t k = 1; k < n_parts; k++) {
+        const float4 v = reinterpret_cast<const float4*>(parts.p[k])[i];
+        s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+}
+
 }  // namespace ptmi_dev
 
 namespace ptmi_internal {
+
+int launch_sum_images(float* out, const float* const* parts, uint32_t n_parts, size_t n_floats, void* stream, std::string* err)
+{
+    if (n_parts == 0 || n_parts > PTMI_MAX_DEVICES || (n_floats & 3u)) {
+        if (err) *err = "launch_sum_images: bad part count or a float count that is not a multiple of 4";
+        return PTMI_ERR_INVALID_ARGUMENT;
+    }
+    ptmi_dev::ImageParts ip{};
+    for (uint32_t k = 0; k < n_parts; k++) ip.p[k] = parts[k];
+    const size_t n_quads = n_floats / 4;
+    hipLaunchKernelGGL(ptmi_dev::sum_images_kernel, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, ip,
+                       n_parts, n_quads);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("sum_images_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    return PTMI_OK;
+}
 
 int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint8_t* out, uint32_t width, uint32_t height,
                        uint32_t row_stride, void* stream, std::string* err)

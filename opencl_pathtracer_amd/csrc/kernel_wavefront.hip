@@ -121,7 +121,8 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
 template <bool STATS, bool PRE, bool SS>
 __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc, const uint32_t first_iteration,
-                                                                    const uint32_t n_iterations, const uint32_t n_jobs,
+                                                                    const uint32_t n_iterations, const uint32_t iteration_stride,
+                                                                    const uint32_t n_jobs,
                                                                     uint32_t* __restrict__ job_counter,
                                                                     const uint32_t stack_levels,
                                                                     float* __restrict__ stage,
@@ -160,7 +161,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // Whether a lane has a path in flight, or is done for good, is kept IN `cur` (REF_IDLE / REF_DEAD) so that the
     // wave's three step masks come from three integer compares; the two bools below only live inside a path-logic trip.
     bool alive = true, need_path = true;
-    uint32_t gx = 0, gy = 0, it = first_iteration;
+    // iteration ids of this launch: first_iteration + k * iteration_stride, k = it_local < n_iterations (the stride is the
+    // number of devices that share a render: each takes the ids of its own residue class, ptmi_api.cpp)
+    uint32_t gx = 0, gy = 0, it_local = 0;
     // path
     int seed = 1;
     float sample_x = 0, sample_y = 0;
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         }
         if (owns_pixel) {
             // JITTERED / UNIFORM: the sample lands on the work-item's own pixel (:1333-1336); stage it
-            const size_t slot = (size_t)(it - first_iteration) * ((size_t)sc.width * sc.height) + (size_t)gy * sc.width + gx;
+            const size_t slot = (size_t)it_local * ((size_t)sc.width * sc.height) + (size_t)gy * sc.width + gx;
             reinterpret_cast<float4*>(stage)[slot] = make_float4(radiance.x, radiance.y, radiance.z, radiance.w);
             // ... and its three histogram bins in one word; histogram_staged_kernel counts them afterwards in LDS.
             // (Three global atomics per path on a handful of hot bins cost 3 % on the 1M-triangle scene and 79 % on the
@@ -468,11 +471,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     // about the same time) send their camera rays and first shadow rays through the same part of the tree
                     const uint32_t unit = job >> 6, in_tile = job & 63u;
                     const uint32_t tile_in_q = unit / n_iterations;
-                    const uint32_t it_local = unit - tile_in_q * n_iterations;
+                    it_local = unit - tile_in_q * n_iterations;
                     const uint32_t tile = tile_lo + tile_in_q;
                     gx = (tile % tiles_x) * 8u + (in_tile & 7u);
                     gy = (tile / tiles_x) * 8u + (in_tile >> 3);
-                    it = first_iteration + it_local;
                     got_job = gx < sc.width && gy < sc.height;  // edge tiles: pixel outside the image, ask again
                 }  // else: the queue ran out under this wave; the lane asks again in the next pass
             }
@@ -485,6 +487,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         if (want_post) {
             // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
             if (got_job) {
+                const uint32_t it = first_iteration + it_local * iteration_stride;
                 seed = lcg_seed(gx, gy, sc.width, sc.height, it);
                 draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
                 {
@@ -615,7 +618,10 @@ __global__ void __launch_bounds__(256) accumulate_staged_ss_kernel(float* __rest
     image_ray_nb[p] = n_after;
     reinterpret_cast<float4*>(image_color)[p] = after;
     float4 v = make_float4(0, 0, 0, 0);
-    if (iteration != 0) {
+    // n_before == 0 with iteration != 0: the first sample THIS context adds to the pixel (a shard of a multi-device
+    // render that does not start at iteration 0, or a cleared context).  The reference would divide 0 by 0 there and keep
+    // a NaN variance for good; a first sample has no deviation, exactly like iteration 0.
+    if (iteration != 0 && n_before != 0.f) {
         v = reinterpret_cast<const float4*>(image_v)[p];
         v.x = v.x + (r.x - before.x / n_before) * (r.x - after.x / n_after);
         v.y = v.y + (r.y - before.y / n_before) * (r.y - after.y / n_after);
@@ -655,7 +661,7 @@ int wavefront_resident_blocks(int device, uint32_t stack_levels)
 }
 
 int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
-                            uint32_t n_iterations, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
+                            uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
                             bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
@@ -684,7 +690,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         warm.wide_records = sc.wide_records;
 #define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
     hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
-                       first_iteration, n_iterations, n_jobs, job_counter, lv, stage, stage_stats)
+                       first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)
 #define PTMI_LAUNCH_WF(S, P, A)                                                                                       \
     PTMI_LAUNCH_WF_IMPL(S, P, A)
         // instantiations: the common case (no statistics, no adaptive sampling) pays for neither

@@ -150,7 +150,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
 
 template <bool PRE>
 __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const uint32_t first_iteration,
-                                                        const uint32_t n_iterations)
+                                                        const uint32_t n_iterations, const uint32_t iteration_stride)
 {
     __shared__ uint32_t stack_mem[kStackDepth * kBlock];
     __shared__ unsigned long long block_counters[C_COUNT];
@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const u
             sum = v4(*reinterpret_cast<const float4*>(&sc.image_color[4 * own_offset]));
             count = sc.image_ray_nb[own_offset];
         }
-        for (uint32_t it = first_iteration; it < first_iteration + n_iterations; it++) {
+        for (uint32_t k = 0; k < n_iterations; k++) {
+            const uint32_t it = first_iteration + k * iteration_stride;
             float sx, sy;
             uint32_t depth;
             PathCounters pc;
@@ -223,16 +224,17 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const u
 
 namespace ptmi_internal {
 
-int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, void* stream, std::string* err)
+int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t iteration_stride, void* stream,
+                  std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
     const dim3 grid((sc.width + 15u) / 16u, (sc.height + 15u) / 16u);
     if (sc.tris_precomputed)
         hipLaunchKernelGGL(ptmi_dev::render_kernel<true>, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
-                           first_iteration, n_iterations);
+                           first_iteration, n_iterations, iteration_stride);
     else
         hipLaunchKernelGGL(ptmi_dev::render_kernel<false>, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
-                           first_iteration, n_iterations);
+                           first_iteration, n_iterations, iteration_stride);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("render_kernel launch: ") + hipGetErrorString(e);

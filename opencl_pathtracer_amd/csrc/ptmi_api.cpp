@@ -35,35 +35,56 @@ void ptmi_internal::set_global_error(const std::string& msg)
     g_err = msg;
 }
 
-struct ptmi_ctx {
-    ptmi_config cfg{};
+// One device's share of a render: a full scene replica, its own accumulators and stream (one process drives all of
+// them from one host thread: every launch and copy below is asynchronous).
+struct DeviceState {
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    bool have_scene = false;
-    std::string err;
-
-    // device memory owned by the context
-    std::vector<void*> allocations;
+    hipStream_t stream = nullptr;       // render stream (own_stream unless ptmi_set_stream gave another)
+    hipStream_t copy_stream = nullptr;  // devices[0]: readbacks; other devices: their peer copy onto devices[0]
+    std::vector<void*> allocations;     // freed with the scene
     float* d_color = nullptr;
     float* d_count = nullptr;
-    bool accum_bound = false;  // caller-owned accumulators
     uint32_t* d_hist = nullptr;  // depths | bbx | tri
     unsigned long long* d_counters = nullptr;
     uint32_t* d_job_counter = nullptr;
-    uint8_t* d_display = nullptr;    // B,G,R scanlines of ptmi_read_display
-    size_t display_bytes = 0;
-    float* d_stage = nullptr;        // staged radiances [iteration][pixel] float4 of the launch in flight
+    float* d_stage = nullptr;  // staged radiances [iteration][pixel] float4 (+ one statistics word) of the launch in flight
     size_t stage_iterations = 0;
     int resident_blocks = 0;
-    uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     DScene ds{};
     DScene* d_scene = nullptr;  // device copy of ds (what the wavefront kernel's path logic reads)
+    // ptmi_snapshot ring: float[5*W*H] per slot (colour, then count), allocated on first use
+    float* d_snapshot[PTMI_MAX_SNAPSHOT_SLOTS] = {};
+    hipEvent_t snapshot_ready[PTMI_MAX_SNAPSHOT_SLOTS] = {};
+    float* d_peer_copy = nullptr;      // devices[0] only: where device k's snapshot lands before the sum, one per device
+    hipEvent_t peer_copied = nullptr;  // ... and the event that says it has
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     double kernel_ms = 0;
     uint32_t kernel_launches = 0;
+};
+
+struct ptmi_ctx {
+    ptmi_config cfg{};
+    std::vector<DeviceState> dev;  // dev[0] = devices[0]: where partial images are summed and read back from
+    bool have_scene = false;
+    bool accum_bound = false;  // caller-owned accumulators (single device)
+    std::string err;
+    uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
+    uint32_t iterations_per_launch = kMaxIterationsPerLaunch;
+
+    // on devices[0]
+    float* d_reduced = nullptr;    // sum of the devices' snapshots (n_devices > 1)
+    uint8_t* d_display = nullptr;  // B,G,R scanlines of ptmi_read_display
+    size_t display_bytes = 0;
+    // host side of the readbacks
+    float* h_staging = nullptr;  // pinned, 5*W*H floats
+    struct HostRange { void* p; size_t bytes; bool registered; };
+    std::vector<HostRange> seen_host;  // destination buffers seen so far; one seen twice is page-locked in place
+
+    size_t npix() const { return (size_t)cfg.image_width * cfg.image_height; }
+    uint32_t n_dev() const { return (uint32_t)dev.size(); }
 };
 
 namespace {
@@ -82,18 +103,35 @@ int fail(ptmi_ctx* ctx, int code, const std::string& msg)
             return fail(ctx, PTMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
     } while (0)
 
+// every device call below is made with the target device current
+#define ON_DEVICE(ctx, d) HIP_TRY(ctx, hipSetDevice((d).device))
+
 void free_scene_memory(ptmi_ctx* ctx)
 {
-    for (void* p : ctx->allocations) (void)hipFree(p);
-    ctx->allocations.clear();
-    ctx->d_color = ctx->d_count = nullptr;
-    ctx->d_hist = nullptr;
-    ctx->d_counters = nullptr;
-    ctx->d_job_counter = nullptr;
-    ctx->d_scene = nullptr;
-    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
-    ctx->d_stage = nullptr;
-    ctx->stage_iterations = 0;
+    for (DeviceState& d : ctx->dev) {
+        (void)hipSetDevice(d.device);
+        (void)hipStreamSynchronize(d.stream);
+        if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
+        for (void* p : d.allocations) (void)hipFree(p);
+        d.allocations.clear();
+        d.d_color = d.d_count = nullptr;
+        d.d_hist = nullptr;
+        d.d_counters = nullptr;
+        d.d_job_counter = nullptr;
+        d.d_scene = nullptr;
+        if (d.d_stage) (void)hipFree(d.d_stage);
+        d.d_stage = nullptr;
+        d.stage_iterations = 0;
+        for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++) {
+            if (d.d_snapshot[k]) (void)hipFree(d.d_snapshot[k]);
+            d.d_snapshot[k] = nullptr;
+        }
+        if (d.d_peer_copy) (void)hipFree(d.d_peer_copy);
+        d.d_peer_copy = nullptr;
+    }
+    if (!ctx->dev.empty()) (void)hipSetDevice(ctx->dev[0].device);
+    if (ctx->d_reduced) (void)hipFree(ctx->d_reduced);
+    ctx->d_reduced = nullptr;
     if (ctx->d_display) (void)hipFree(ctx->d_display);
     ctx->d_display = nullptr;
     ctx->display_bytes = 0;
@@ -102,15 +140,29 @@ void free_scene_memory(ptmi_ctx* ctx)
 }
 
 template <class T>
-int upload(ptmi_ctx* ctx, const std::vector<T>& host, const T** out)
+int upload(ptmi_ctx* ctx, DeviceState& d, const T* host, size_t count, const T** out)
 {
-    const size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);  // reference uploads >= 1 byte (OpenCL.cpp:165)
-    void* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, bytes));
-    ctx->allocations.push_back(d);
-    // blocking copy: the staging vectors are pageable and short-lived
-    if (!host.empty()) HIP_TRY(ctx, hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-    *out = static_cast<const T*>(d);
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);  // reference uploads >= 1 byte (OpenCL.cpp:165)
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    d.allocations.push_back(p);
+    // blocking copy: the source is pageable host memory
+    if (count) HIP_TRY(ctx, hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return PTMI_OK;
+}
+template <class T>
+int upload(ptmi_ctx* ctx, DeviceState& d, const std::vector<T>& host, const T** out)
+{
+    return upload(ctx, d, host.data(), host.size(), out);
+}
+
+int device_alloc(ptmi_ctx* ctx, DeviceState& d, size_t bytes, void** out)
+{
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    d.allocations.push_back(p);
+    *out = p;
     return PTMI_OK;
 }
 
@@ -146,6 +198,7 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
     if (sc->materiaux_size && !sc->materiaux) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "materiaux is NULL");
     if (!sc->sky) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "sky is NULL");
     if (sc->textures_data_size && !sc->textures_data) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "textures_data is NULL");
+    if (sc->textures_size && !sc->textures) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "textures is NULL");
     if (sc->lights_size != ctx->cfg.lights_size)
         return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "scene.lights_size differs from config.lights_size (LIGHTS_SIZE is baked at setup)");
 
@@ -241,7 +294,10 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
             out.recs.push_back(out.tris[n.triangle_start_index + k]);
             out.tri_ids.push_back(n.triangle_start_index + k);
         }
-        uint32_t r = (n.triangles_aabb.is_empty ? REF_EMPTY : 0u) | REF_LEAF;
+        // A leaf without triangles is stored as an EMPTY child: never descended, which gives the reference's results and
+        // counters (its box is still tested and counted; visiting it would test nothing) and keeps the wavefront
+        // kernel's invariant that a decoded leaf leaves a non-empty triangle range behind.
+        uint32_t r = ((n.triangles_aabb.is_empty || n.nb_triangles == 0) ? REF_EMPTY : 0u) | REF_LEAF;
         if (n.nb_triangles < REF_COUNT_BIG) {
             r |= (n.nb_triangles << REF_COUNT_SHIFT) | (uint32_t)start;
         } else {
@@ -315,25 +371,288 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
     return PTMI_OK;
 }
 
-int fold_events(ptmi_ctx* ctx)
+int fold_events(ptmi_ctx* ctx, DeviceState& d)
 {
-    for (auto& ev : ctx->pending_events) {
+    ON_DEVICE(ctx, d);
+    for (auto& ev : d.pending_events) {
         float ms = 0;
         HIP_TRY(ctx, hipEventSynchronize(ev.second));
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
-        ctx->kernel_ms += ms;
-        ctx->kernel_launches++;
-        ctx->free_events.push_back(ev);
+        d.kernel_ms += ms;
+        d.kernel_launches++;
+        d.free_events.push_back(ev);
     }
-    ctx->pending_events.clear();
+    d.pending_events.clear();
     return PTMI_OK;
 }
+
+// Everything of a scene that lives on one device: the re-laid-out records, the accumulators, the statistics.
+int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_scene* sc)
+{
+    ON_DEVICE(ctx, d);
+    DScene& ds = d.ds;
+    ds = DScene{};
+    if (int rc = upload(ctx, d, lay.recs, &ds.tris)) return rc;
+    ds.nodes = reinterpret_cast<const DNode*>(ds.tris);  // same array: a reference is an index of 64-byte records
+    ds.n_records = (uint32_t)lay.recs.size();
+    ds.wide_records = (lay.recs.size() > (1u << 26) || std::getenv("PTMI_WIDE_RECORDS") != nullptr) ? 1u : 0u;  // env: test switch
+    if (int rc = upload(ctx, d, lay.tri_ids, &ds.tri_ids)) return rc;
+    if (int rc = upload(ctx, d, lay.shade, &ds.shade)) return rc;
+    if (int rc = upload(ctx, d, lay.mats, &ds.mats)) return rc;
+    if (int rc = upload(ctx, d, lay.big_leaves, &ds.big_leaves)) return rc;
+    if (int rc = upload(ctx, d, sc->lights, sc->lights_size, &ds.lights)) return rc;
+    if (int rc = upload(ctx, d, sc->textures, sc->textures_size, &ds.textures)) return rc;
+    if (int rc = upload(ctx, d, sc->textures_data, sc->textures_data_size, &ds.texels)) return rc;
+
+    const size_t npix = ctx->npix();
+    const size_t hist_words = (size_t)ctx->cfg.ray_max_depth + 1 + 2 * PTMI_MAX_INTERSECTION_NUMBER;
+    void *dc = nullptr, *dn = nullptr, *dh = nullptr, *dk = nullptr, *dsc = nullptr;
+    if (int rc = device_alloc(ctx, d, npix * 16, &dc)) return rc;
+    if (int rc = device_alloc(ctx, d, npix * 4, &dn)) return rc;
+    if (int rc = device_alloc(ctx, d, hist_words * 4, &dh)) return rc;
+    // counters, then the job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart)
+    if (int rc = device_alloc(ctx, d, C_COUNT * 8 + 256 + 8 * 1024 * 4, &dk)) return rc;
+    if (int rc = device_alloc(ctx, d, sizeof(DScene), &dsc)) return rc;
+    d.d_scene = (DScene*)dsc;
+    d.d_color = (float*)dc; d.d_count = (float*)dn; d.d_hist = (uint32_t*)dh;
+    d.d_counters = (unsigned long long*)dk;
+    d.d_job_counter = (uint32_t*)((char*)dk + ((C_COUNT * 8 + 255) / 256) * 256);
+
+    ds.image_color = d.d_color;
+    ds.image_ray_nb = d.d_count;
+    const bool hist = !(ctx->cfg.flags & PTMI_FLAG_NO_HISTOGRAMS);
+    ds.hist_depths = hist ? d.d_hist : nullptr;
+    ds.hist_bbx = hist ? d.d_hist + ctx->cfg.ray_max_depth + 1 : nullptr;
+    ds.hist_tri = hist ? d.d_hist + ctx->cfg.ray_max_depth + 1 + PTMI_MAX_INTERSECTION_NUMBER : nullptr;
+    ds.counters = d.d_counters;
+    ds.super_sampling = ctx->cfg.super_sampling ? 1u : 0u;
+    if (ds.super_sampling) {
+        void *dv = nullptr, *dx = nullptr, *df = nullptr;
+        if (int rc = device_alloc(ctx, d, npix * 16, &dv)) return rc;
+        if (int rc = device_alloc(ctx, d, sizeof kX2inv, &dx)) return rc;
+        if (int rc = device_alloc(ctx, d, npix * 4, &df)) return rc;
+        HIP_TRY(ctx, hipMemcpy(dx, kX2inv, sizeof kX2inv, hipMemcpyHostToDevice));
+        ds.image_v = (float*)dv; ds.x2inv = (const float*)dx; ds.stage_flag = (float*)df;
+    }
+    ds.sky = *sc->sky;
+    std::memcpy(ds.cam_pos, &sc->camera_position, 16);
+    std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
+    std::memcpy(ds.cam_right, &sc->camera_right, 16);
+    std::memcpy(ds.cam_up, &sc->camera_up, 16);
+    d.resident_blocks = wavefront_resident_blocks(d.device, ctx->stack_levels);
+    ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
+    ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
+    ds.root_ref = lay.root_ref;
+    ds.width = ctx->cfg.image_width;
+    ds.height = ctx->cfg.image_height;
+    ds.max_depth = ctx->cfg.ray_max_depth;
+    ds.n_lights = ctx->cfg.lights_size;
+    ds.sampler = ctx->cfg.sampler;
+    HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
+    return PTMI_OK;
+}
+
+// Iteration ids [first, first + n) that device k of G takes: those congruent to k modulo G.
+void device_share(uint32_t first, uint32_t n, uint32_t k, uint32_t G, uint32_t* first_k, uint32_t* n_k)
+{
+    const uint32_t skip = (k + G - first % G) % G;  // ids to skip from `first` to the first one of class k
+    *first_k = first + skip;
+    *n_k = skip < n ? (n - skip + G - 1) / G : 0;
+}
+
+// One device's launches for its share of a ptmi_render call, bracketed by an event pair for ptmi_kernel_time.
+int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, uint32_t stride)
+{
+    if (n == 0) return PTMI_OK;
+    ON_DEVICE(ctx, d);
+    if (d.pending_events.size() >= 512)
+        if (int rc = fold_events(ctx, d)) return rc;
+    const bool megakernel = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0;
+    const size_t npix = ctx->npix();
+    if (!megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM) {
+        // staging array for the launch: grows on demand, capped by iterations_per_launch
+        const size_t want = n < ctx->iterations_per_launch ? n : ctx->iterations_per_launch;
+        if (want > d.stage_iterations) {
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+            if (d.d_stage) (void)hipFree(d.d_stage);
+            d.d_stage = nullptr;
+            d.stage_iterations = 0;
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, want * npix * 20));  // float4 radiance + one statistics word per path
+            d.d_stage = (float*)p;
+            d.stage_iterations = want;
+        }
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (!d.free_events.empty()) {
+        ev = d.free_events.back();
+        d.free_events.pop_back();
+    } else {
+        HIP_TRY(ctx, hipEventCreate(&ev.first));
+        if (hipEventCreate(&ev.second) != hipSuccess) {
+            (void)hipEventDestroy(ev.first);
+            return fail(ctx, PTMI_ERR_HIP, "hipEventCreate failed");
+        }
+    }
+    std::string err;
+    int rc = PTMI_OK;
+    hipError_t e = hipEventRecord(ev.first, d.stream);
+    if (e == hipSuccess) {
+        if (megakernel) {
+            rc = launch_render(d.ds, first, n, stride, d.stream, &err);
+        } else {
+            // histograms: staged per path and counted after the launch, unless there is no staging (RANDOM sampler),
+            // no histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
+            uint32_t* stage_stats = nullptr;
+            if (d.d_stage && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)
+                stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d.d_stage) + d.stage_iterations * npix * 16);
+            // one launch per chunk of iterations; chunks run back to back on the stream, in order
+            for (uint32_t done = 0; done < n && rc == PTMI_OK;) {
+                // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
+                const uint32_t cap = ctx->cfg.super_sampling ? 1u : ctx->iterations_per_launch;
+                const uint32_t m = n - done < cap ? n - done : cap;
+                rc = launch_render_wavefront(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter, d.resident_blocks,
+                                             ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, d.d_stage,
+                                             stage_stats, d.stream, &err);
+                done += m;
+            }
+        }
+        e = hipEventRecord(ev.second, d.stream);
+    }
+    if (e != hipSuccess || rc != PTMI_OK) {
+        d.free_events.push_back(ev);  // never timed: back to the pool
+        if (rc != PTMI_OK) return fail(ctx, rc, err);
+        return fail(ctx, PTMI_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+    }
+    d.pending_events.push_back(ev);
+    return PTMI_OK;
+}
+
+// Host buffer `p` as the destination of an asynchronous copy: page-locked in place from the second time it is seen
+// (the viewer's buffers, handed in after every image), through the context's pinned staging buffer before that.
+bool host_is_pinned(ptmi_ctx* ctx, void* p, size_t bytes)
+{
+    for (auto& r : ctx->seen_host) {
+        if (r.p != p || r.bytes != bytes) continue;
+        if (!r.registered && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) r.registered = true;
+        else if (!r.registered) (void)hipGetLastError();  // not registrable (already pinned elsewhere, odd mapping): staging
+        return r.registered;
+    }
+    if (ctx->seen_host.size() < 8) ctx->seen_host.push_back({p, bytes, false});
+    return false;
+}
+
+int ensure_staging(ptmi_ctx* ctx)
+{
+    if (!ctx->h_staging) {
+        void* p = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&p, ctx->npix() * 20, hipHostMallocDefault));
+        ctx->h_staging = (float*)p;
+    }
+    return PTMI_OK;
+}
+
+// Device float[4*npix] / float[npix] -> the caller's buffers over devices[0]'s `stream`, then wait for that stream.
+int copy_out(ptmi_ctx* ctx, hipStream_t stream, const float* d_color, const float* d_count, float* image_color, float* image_ray_nb)
+{
+    const size_t npix = ctx->npix();
+    const bool pin_c = image_color && host_is_pinned(ctx, image_color, npix * 16);
+    const bool pin_n = image_ray_nb && host_is_pinned(ctx, image_ray_nb, npix * 4);
+    if ((image_color && !pin_c) || (image_ray_nb && !pin_n))
+        if (int rc = ensure_staging(ctx)) return rc;
+    if (image_color)
+        HIP_TRY(ctx, hipMemcpyAsync(pin_c ? image_color : ctx->h_staging, d_color, npix * 16, hipMemcpyDeviceToHost, stream));
+    if (image_ray_nb)
+        HIP_TRY(ctx, hipMemcpyAsync(pin_n ? image_ray_nb : ctx->h_staging + 4 * npix, d_count, npix * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (image_color && !pin_c) std::memcpy(image_color, ctx->h_staging, npix * 16);
+    if (image_ray_nb && !pin_n) std::memcpy(image_ray_nb, ctx->h_staging + 4 * npix, npix * 4);
+    return PTMI_OK;
+}
+
+// Queue, behind everything each device has been given so far, a copy of its accumulators into ring slot `slot`.
+int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
+{
+    const size_t npix = ctx->npix();
+    for (DeviceState& d : ctx->dev) {
+        ON_DEVICE(ctx, d);
+        if (!d.d_snapshot[slot]) {
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, npix * 20));
+            d.d_snapshot[slot] = (float*)p;
+        }
+        if (!d.snapshot_ready[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.snapshot_ready[slot], hipEventDisableTiming));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot], d.ds.image_color, npix * 16, hipMemcpyDeviceToDevice, d.stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot] + 4 * npix, d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToDevice, d.stream));
+        HIP_TRY(ctx, hipEventRecord(d.snapshot_ready[slot], d.stream));
+    }
+    return PTMI_OK;
+}
+
+// The image of ring slot `slot` on devices[0], ordered on dev[0].copy_stream: the slot itself for one device; for several,
+// every other device's snapshot copied over (each on its own stream, so the transfers use their own xGMI links at the same
+// time) and the sum of all of them, in device order, in ctx->d_reduced.
+int gather_snapshot(ptmi_ctx* ctx, uint32_t slot, const float** image)
+{
+    DeviceState& lead = ctx->dev[0];
+    const size_t npix = ctx->npix();
+    for (DeviceState& d : ctx->dev)
+        if (!d.snapshot_ready[slot]) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot of a slot no ptmi_snapshot has filled");
+    ON_DEVICE(ctx, lead);
+    HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, lead.snapshot_ready[slot], 0));
+    if (ctx->n_dev() == 1) {
+        *image = lead.d_snapshot[slot];
+        return PTMI_OK;
+    }
+    const float* parts[PTMI_MAX_DEVICES];
+    parts[0] = lead.d_snapshot[slot];
+    for (uint32_t k = 1; k < ctx->n_dev(); k++) {
+        DeviceState& d = ctx->dev[k];
+        if (!d.d_peer_copy) {
+            void* p = nullptr;
+            HIP_TRY(ctx, hipMalloc(&p, npix * 20));  // on devices[0]: the lead device is current
+            d.d_peer_copy = (float*)p;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&d.peer_copied, hipEventDisableTiming));
+        }
+        // the previous sum must have read this buffer before it is overwritten: copy_stream order covers it, because the
+        // copy below waits for the lead's copy stream through an event recorded there
+        hipEvent_t& gate = lead.peer_copied;
+        if (!gate) HIP_TRY(ctx, hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(gate, lead.copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, gate, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, d.snapshot_ready[slot], 0));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_peer_copy, lead.device, d.d_snapshot[slot], d.device, npix * 20, d.copy_stream));
+        HIP_TRY(ctx, hipEventRecord(d.peer_copied, d.copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, d.peer_copied, 0));
+        parts[k] = d.d_peer_copy;
+    }
+    if (!ctx->d_reduced) {
+        void* p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, npix * 20));
+        ctx->d_reduced = (float*)p;
+    }
+    std::string err;
+    if (int rc = launch_sum_images(ctx->d_reduced, parts, ctx->n_dev(), npix * 5, lead.copy_stream, &err)) return fail(ctx, rc, err);
+    *image = ctx->d_reduced;
+    return PTMI_OK;
+}
+
+constexpr uint32_t kInternalSlot = PTMI_MAX_SNAPSHOT_SLOTS - 1;  // ptmi_read_image / ptmi_read_display of a multi-device context
 
 }  // namespace
 
 extern "C" {
 
 int ptmi_abi_version(void) { return PTMI_ABI_VERSION; }
+
+void ptmi_device_share(uint32_t first_iteration, uint32_t n_iterations, uint32_t k, uint32_t n_devices, uint32_t* first_k,
+                       uint32_t* n_k)
+{
+    uint32_t f = first_iteration, n = 0;
+    if (n_devices > 0 && k < n_devices) device_share(first_iteration, n_iterations, k, n_devices, &f, &n);
+    if (first_k) *first_k = f;
+    if (n_k) *n_k = n;
+}
 
 int ptmi_device_count(void)
 {
@@ -362,26 +681,56 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
     if (cfg->sampler > PTMI_SAMPLER_UNIFORM) return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "unknown sampler");
     if (cfg->lights_size >= PTMI_MAX_LIGHT_SIZE)  // PathTracer.cpp:60-65
         return fail(nullptr, PTMI_ERR_LIMIT, "lights_size >= 30");
+    if (cfg->n_devices > PTMI_MAX_DEVICES) return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "n_devices > PTMI_MAX_DEVICES");
     if (cfg->super_sampling && (cfg->sampler == PTMI_SAMPLER_RANDOM || (cfg->flags & PTMI_FLAG_MEGAKERNEL)))
         return fail(nullptr, PTMI_ERR_UNSUPPORTED,
                     "SUPER_SAMPLING needs a sampler that owns its pixel (JITTERED/UNIFORM) and the wavefront kernel");
+    if (cfg->super_sampling && cfg->n_devices > 1)
+        return fail(nullptr, PTMI_ERR_UNSUPPORTED,
+                    "SUPER_SAMPLING on several devices: the variance image does not merge by a sum (one context per device and "
+                    "distributed.reduce_super_sampling instead)");
 
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(nullptr, PTMI_ERR_NO_DEVICE, "no HIP device available (there is no CPU fallback)");
-    if (cfg->device < 0 || cfg->device >= n) return fail(nullptr, PTMI_ERR_NO_DEVICE, "device ordinal out of range");
+    std::vector<int> ordinals;
+    if (cfg->n_devices <= 1) ordinals.push_back(cfg->n_devices == 1 ? cfg->devices[0] : cfg->device);
+    else ordinals.assign(cfg->devices, cfg->devices + cfg->n_devices);
+    for (int o : ordinals)
+        if (o < 0 || o >= n) return fail(nullptr, PTMI_ERR_NO_DEVICE, "device ordinal out of range");
 
     ptmi_ctx* ctx = new ptmi_ctx();
     ctx->cfg = *cfg;
-    ctx->device = cfg->device;
-    hipError_t e = hipSetDevice(ctx->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    ctx->dev.resize(ordinals.size());
+    hipError_t e = hipSuccess;
+    for (size_t k = 0; k < ordinals.size() && e == hipSuccess; k++) {
+        DeviceState& d = ctx->dev[k];
+        d.device = ordinals[k];
+        e = hipSetDevice(d.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.own_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking);
+        d.stream = d.own_stream;
+        if (e == hipSuccess && k > 0 && d.device != ordinals[0]) {
+            // direct peer copies over xGMI where the platform allows them (hipMemcpyPeerAsync stages through the host otherwise)
+            (void)hipDeviceEnablePeerAccess(ordinals[0], 0);
+            (void)hipGetLastError();
+        }
+    }
     if (e != hipSuccess) {
         const std::string msg = std::string("device/stream setup: ") + hipGetErrorString(e);
-        delete ctx;
+        ptmi_release(ctx);
         return fail(nullptr, PTMI_ERR_HIP, msg);
     }
-    ctx->stream = ctx->own_stream;
+    // iterations per launch: at most 16, fewer for very large images (32-bit job ids, staging array <= 4 GiB)
+    {
+        const uint64_t tiles = (uint64_t)((cfg->image_width + 7u) / 8u) * ((cfg->image_height + 7u) / 8u);
+        const uint64_t by_jobs = 0xFFFFFFF0ull / (tiles * 64u);
+        const uint64_t by_bytes = (4ull << 30) / ((uint64_t)cfg->image_width * cfg->image_height * 20u);
+        uint64_t cap = kMaxIterationsPerLaunch;
+        if (by_jobs < cap) cap = by_jobs;
+        if (by_bytes < cap) cap = by_bytes;
+        ctx->iterations_per_launch = cap < 1 ? 1u : (uint32_t)cap;
+    }
     *out = ctx;
     return PTMI_OK;
 }
@@ -389,10 +738,12 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
 int ptmi_set_stream(ptmi_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (int rc = fold_events(ctx)) return rc;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (ctx->n_dev() != 1) return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_set_stream on a multi-device context");
+    DeviceState& d = ctx->dev[0];
+    ON_DEVICE(ctx, d);
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    if (int rc = fold_events(ctx, d)) return rc;
+    d.stream = hip_stream ? (hipStream_t)hip_stream : d.own_stream;
     return PTMI_OK;
 }
 
@@ -401,99 +752,38 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!sc || sc->struct_size != sizeof(ptmi_scene))
         return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "scene is NULL or struct_size mismatch (ABI)");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene_memory(ctx);
 
     Relayout lay;
     if (int rc = build_layout(ctx, sc, lay)) return rc;
-
-    DScene& ds = ctx->ds;
-    ds = DScene{};
-    if (int rc = upload(ctx, lay.recs, &ds.tris)) return rc;
-    ds.nodes = reinterpret_cast<const DNode*>(ds.tris);  // same array: a reference is an index of 64-byte records
-    ds.n_records = (uint32_t)lay.recs.size();
-    ds.wide_records = (lay.recs.size() > (1u << 26) || std::getenv("PTMI_WIDE_RECORDS") != nullptr) ? 1u : 0u;  // env: test switch
-    if (int rc = upload(ctx, lay.tri_ids, &ds.tri_ids)) return rc;
-    if (int rc = upload(ctx, lay.shade, &ds.shade)) return rc;
-    if (int rc = upload(ctx, lay.mats, &ds.mats)) return rc;
-    if (int rc = upload(ctx, lay.big_leaves, &ds.big_leaves)) return rc;
-    {
-        std::vector<ptmi_light> v(sc->lights, sc->lights + sc->lights_size);
-        if (int rc = upload(ctx, v, &ds.lights)) return rc;
-        std::vector<ptmi_texture> t(sc->textures, sc->textures + sc->textures_size);
-        if (int rc = upload(ctx, t, &ds.textures)) return rc;
-        std::vector<ptmi_uchar4> x(sc->textures_data, sc->textures_data + sc->textures_data_size);
-        if (int rc = upload(ctx, x, &ds.texels)) return rc;
-    }
-
-    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
-    const size_t hist_words = (size_t)ctx->cfg.ray_max_depth + 1 + 2 * PTMI_MAX_INTERSECTION_NUMBER;
-    void *dc = nullptr, *dn = nullptr, *dh = nullptr, *dk = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dc, npix * 16)); ctx->allocations.push_back(dc);
-    HIP_TRY(ctx, hipMalloc(&dn, npix * 4));  ctx->allocations.push_back(dn);
-    HIP_TRY(ctx, hipMalloc(&dh, hist_words * 4)); ctx->allocations.push_back(dh);
-    // counters, then the job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart)
-    HIP_TRY(ctx, hipMalloc(&dk, C_COUNT * 8 + 256 + 8 * 1024 * 4)); ctx->allocations.push_back(dk);
-    void* dsc = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dsc, sizeof(DScene))); ctx->allocations.push_back(dsc);
-    ctx->d_scene = (DScene*)dsc;
-    ctx->d_color = (float*)dc; ctx->d_count = (float*)dn; ctx->d_hist = (uint32_t*)dh;
-    ctx->d_counters = (unsigned long long*)dk;
-    ctx->d_job_counter = (uint32_t*)((char*)dk + ((C_COUNT * 8 + 255) / 256) * 256);
-
-    ds.image_color = ctx->d_color;
-    ds.image_ray_nb = ctx->d_count;
-    const bool hist = !(ctx->cfg.flags & PTMI_FLAG_NO_HISTOGRAMS);
-    ds.hist_depths = hist ? ctx->d_hist : nullptr;
-    ds.hist_bbx = hist ? ctx->d_hist + ctx->cfg.ray_max_depth + 1 : nullptr;
-    ds.hist_tri = hist ? ctx->d_hist + ctx->cfg.ray_max_depth + 1 + PTMI_MAX_INTERSECTION_NUMBER : nullptr;
-    ds.counters = ctx->d_counters;
-    ds.super_sampling = ctx->cfg.super_sampling ? 1u : 0u;
-    if (ds.super_sampling) {
-        void *dv = nullptr, *dx = nullptr, *df = nullptr;
-        HIP_TRY(ctx, hipMalloc(&dv, npix * 16)); ctx->allocations.push_back(dv);
-        HIP_TRY(ctx, hipMalloc(&dx, sizeof kX2inv)); ctx->allocations.push_back(dx);
-        HIP_TRY(ctx, hipMalloc(&df, npix * 4)); ctx->allocations.push_back(df);
-        HIP_TRY(ctx, hipMemcpy(dx, kX2inv, sizeof kX2inv, hipMemcpyHostToDevice));
-        ds.image_v = (float*)dv; ds.x2inv = (const float*)dx; ds.stage_flag = (float*)df;
-    }
-    ds.sky = *sc->sky;
-    std::memcpy(ds.cam_pos, &sc->camera_position, 16);
-    std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
-    std::memcpy(ds.cam_right, &sc->camera_right, 16);
-    std::memcpy(ds.cam_up, &sc->camera_up, 16);
     // a ray holds at most one pending far child per level it has descended
     ctx->stack_levels = lay.max_depth < 1 ? 1 : lay.max_depth;
-    ctx->resident_blocks = wavefront_resident_blocks(ctx->device, ctx->stack_levels);
-    ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
-    ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
-    ds.root_ref = lay.root_ref;
-    ds.width = ctx->cfg.image_width;
-    ds.height = ctx->cfg.image_height;
-    ds.max_depth = ctx->cfg.ray_max_depth;
-    ds.n_lights = ctx->cfg.lights_size;
-    ds.sampler = ctx->cfg.sampler;
-
-    HIP_TRY(ctx, hipMemcpy(ctx->d_scene, &ctx->ds, sizeof(DScene), hipMemcpyHostToDevice));
+    for (DeviceState& d : ctx->dev)
+        if (int rc = upload_scene(ctx, d, lay, sc)) {
+            const std::string msg = ctx->err;
+            free_scene_memory(ctx);
+            ctx->err = msg;
+            return rc;
+        }
     ctx->have_scene = true;
     if (int rc = ptmi_clear(ctx)) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
-    return PTMI_OK;
+    return ptmi_synchronize(ctx);
 }
 
 int ptmi_clear(ptmi_ctx* ctx)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_clear before ptmi_initialize_memory");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
+    const size_t npix = ctx->npix();
     const size_t hist_words = (size_t)ctx->cfg.ray_max_depth + 1 + 2 * PTMI_MAX_INTERSECTION_NUMBER;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_color, 0, npix * 16, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_ray_nb, 0, npix * 4, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_hist, 0, hist_words * 4, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, C_COUNT * 8, ctx->stream));
-    if (ctx->ds.image_v) HIP_TRY(ctx, hipMemsetAsync(ctx->ds.image_v, 0, npix * 16, ctx->stream));
+    for (DeviceState& d : ctx->dev) {
+        ON_DEVICE(ctx, d);
+        HIP_TRY(ctx, hipMemsetAsync(d.ds.image_color, 0, npix * 16, d.stream));
+        HIP_TRY(ctx, hipMemsetAsync(d.ds.image_ray_nb, 0, npix * 4, d.stream));
+        HIP_TRY(ctx, hipMemsetAsync(d.d_hist, 0, hist_words * 4, d.stream));
+        HIP_TRY(ctx, hipMemsetAsync(d.d_counters, 0, C_COUNT * 8, d.stream));
+        if (d.ds.image_v) HIP_TRY(ctx, hipMemsetAsync(d.ds.image_v, 0, npix * 16, d.stream));
+    }
     return PTMI_OK;
 }
 
@@ -504,91 +794,82 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
     if (n_iterations == 0) return PTMI_OK;
     if ((uint64_t)first_iteration + n_iterations > 0xFFFFFFFFull)
         return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "iteration range overflows 32 bits");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->pending_events.size() >= 512)
-        if (int rc = fold_events(ctx)) return rc;
-    std::pair<hipEvent_t, hipEvent_t> ev;
-    if (!ctx->free_events.empty()) {
-        ev = ctx->free_events.back();
-        ctx->free_events.pop_back();
-    } else {
-        HIP_TRY(ctx, hipEventCreate(&ev.first));
-        HIP_TRY(ctx, hipEventCreate(&ev.second));
+    const uint32_t G = ctx->n_dev();
+    for (uint32_t k = 0; k < G; k++) {
+        uint32_t first_k, n_k;
+        device_share(first_iteration, n_iterations, k, G, &first_k, &n_k);
+        if (int rc = render_on_device(ctx, ctx->dev[k], first_k, n_k, G)) return rc;
     }
-    const bool megakernel = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0;
-    if (!megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM) {
-        // staging array for the launch: grows on demand, capped by kMaxIterationsPerLaunch
-        const size_t want = n_iterations < kMaxIterationsPerLaunch ? n_iterations : kMaxIterationsPerLaunch;
-        if (want > ctx->stage_iterations) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->d_stage) (void)hipFree(ctx->d_stage);
-            ctx->d_stage = nullptr;
-            ctx->stage_iterations = 0;
-            const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
-            void* p = nullptr;
-            HIP_TRY(ctx, hipMalloc(&p, want * npix * 20));  // float4 radiance + one statistics word per path
-            ctx->d_stage = (float*)p;
-            ctx->stage_iterations = want;
-        }
-    }
-    HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
-    std::string err;
-    int rc = PTMI_OK;
-    if (megakernel) {
-        rc = launch_render(ctx->ds, first_iteration, n_iterations, ctx->stream, &err);
-    } else {
-        // histograms: staged per path and counted after the launch, unless there is no staging (RANDOM sampler),
-        // no histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
-        uint32_t* stage_stats = nullptr;
-        if (ctx->d_stage && ctx->ds.hist_depths && ctx->cfg.ray_max_depth < 64)
-            stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_stage) +
-                                                      ctx->stage_iterations * (size_t)ctx->cfg.image_width * ctx->cfg.image_height * 16);
-        // one launch per chunk of iterations; chunks run back to back on the stream, in order
-        for (uint32_t done = 0; done < n_iterations && rc == PTMI_OK;) {
-            // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
-            const uint32_t cap = ctx->cfg.super_sampling ? 1u : kMaxIterationsPerLaunch;
-            const uint32_t n = n_iterations - done < cap ? n_iterations - done : cap;
-            rc = launch_render_wavefront(ctx->ds, ctx->d_scene, first_iteration + done, n, ctx->d_job_counter, ctx->resident_blocks,
-                                         ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0,
-                                         ctx->d_stage, stage_stats, ctx->stream, &err);
-            done += n;
-        }
-    }
-    HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
-    ctx->pending_events.push_back(ev);
-    if (rc) return fail(ctx, rc, err);
     return PTMI_OK;
 }
 
 int ptmi_synchronize(ptmi_ctx* ctx)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (DeviceState& d : ctx->dev) {
+        ON_DEVICE(ctx, d);
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    }
     return PTMI_OK;
+}
+
+int ptmi_snapshot(ptmi_ctx* ctx, uint32_t slot)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_snapshot before ptmi_initialize_memory");
+    if (slot >= PTMI_MAX_SNAPSHOT_SLOTS) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "snapshot slot out of range");
+    return snapshot_all(ctx, slot);
+}
+
+int ptmi_read_snapshot(ptmi_ctx* ctx, uint32_t slot, float* image_color, float* image_ray_nb)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot before ptmi_initialize_memory");
+    if (slot >= PTMI_MAX_SNAPSHOT_SLOTS) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "snapshot slot out of range");
+    if (!image_color && !image_ray_nb) {  // wait only: the snapshot has been taken on every device (clFinish of that image)
+        for (DeviceState& d : ctx->dev) {
+            if (!d.snapshot_ready[slot]) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot of a slot no ptmi_snapshot has filled");
+            ON_DEVICE(ctx, d);
+            HIP_TRY(ctx, hipEventSynchronize(d.snapshot_ready[slot]));
+        }
+        return PTMI_OK;
+    }
+    const float* image = nullptr;
+    if (int rc = gather_snapshot(ctx, slot, &image)) return rc;
+    return copy_out(ctx, ctx->dev[0].copy_stream, image, image + 4 * ctx->npix(), image_color, image_ray_nb);
 }
 
 int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_image before ptmi_initialize_memory");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
-    if (image_color) HIP_TRY(ctx, hipMemcpyAsync(image_color, ctx->ds.image_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (image_ray_nb) HIP_TRY(ctx, hipMemcpyAsync(image_ray_nb, ctx->ds.image_ray_nb, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PTMI_OK;
+    if (ctx->n_dev() == 1) {  // straight from the accumulators, in order on the render stream
+        DeviceState& d = ctx->dev[0];
+        ON_DEVICE(ctx, d);
+        return copy_out(ctx, d.stream, d.ds.image_color, d.ds.image_ray_nb, image_color, image_ray_nb);
+    }
+    if (int rc = snapshot_all(ctx, kInternalSlot)) return rc;
+    return ptmi_read_snapshot(ctx, kInternalSlot, image_color, image_ray_nb);
 }
 
 int ptmi_write_image(ptmi_ctx* ctx, const float* image_color, const float* image_ray_nb)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_write_image before ptmi_initialize_memory");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
-    if (image_color) HIP_TRY(ctx, hipMemcpy(ctx->ds.image_color, image_color, npix * 16, hipMemcpyHostToDevice));
-    if (image_ray_nb) HIP_TRY(ctx, hipMemcpy(ctx->ds.image_ray_nb, image_ray_nb, npix * 4, hipMemcpyHostToDevice));
+    const size_t npix = ctx->npix();
+    // the image goes to devices[0]; the other devices' partial sums restart from zero
+    for (uint32_t k = 0; k < ctx->n_dev(); k++) {
+        DeviceState& d = ctx->dev[k];
+        ON_DEVICE(ctx, d);
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        if (k == 0) {
+            if (image_color) HIP_TRY(ctx, hipMemcpy(d.ds.image_color, image_color, npix * 16, hipMemcpyHostToDevice));
+            if (image_ray_nb) HIP_TRY(ctx, hipMemcpy(d.ds.image_ray_nb, image_ray_nb, npix * 4, hipMemcpyHostToDevice));
+        } else {
+            if (image_color) HIP_TRY(ctx, hipMemset(d.ds.image_color, 0, npix * 16));
+            if (image_ray_nb) HIP_TRY(ctx, hipMemset(d.ds.image_ray_nb, 0, npix * 4));
+        }
+    }
     return PTMI_OK;
 }
 
@@ -599,7 +880,17 @@ int ptmi_read_display(ptmi_ctx* ctx, uint8_t* bgr, uint32_t row_stride)
     const uint32_t w = ctx->cfg.image_width, h = ctx->cfg.image_height;
     if (row_stride < 3u * w || row_stride > 3u * w + 3u)
         return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "row_stride must be 3*W plus 0..3 padding bytes");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DeviceState& d = ctx->dev[0];
+    const float *color = d.ds.image_color, *count = d.ds.image_ray_nb;
+    hipStream_t stream = d.stream;
+    if (ctx->n_dev() > 1) {
+        if (int rc = snapshot_all(ctx, kInternalSlot)) return rc;
+        const float* image = nullptr;
+        if (int rc = gather_snapshot(ctx, kInternalSlot, &image)) return rc;
+        color = image; count = image + 4 * ctx->npix();
+        stream = d.copy_stream;
+    }
+    ON_DEVICE(ctx, d);
     const size_t bytes = (size_t)h * row_stride;
     if (bytes > ctx->display_bytes) {
         if (ctx->d_display) (void)hipFree(ctx->d_display);
@@ -611,10 +902,9 @@ int ptmi_read_display(ptmi_ctx* ctx, uint8_t* bgr, uint32_t row_stride)
         ctx->display_bytes = bytes;
     }
     std::string err;
-    if (int rc = launch_display_bgr(ctx->ds.image_color, ctx->ds.image_ray_nb, ctx->d_display, w, h, row_stride, ctx->stream, &err))
-        return fail(ctx, rc, err);
-    HIP_TRY(ctx, hipMemcpyAsync(bgr, ctx->d_display, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = launch_display_bgr(color, count, ctx->d_display, w, h, row_stride, stream, &err)) return fail(ctx, rc, err);
+    HIP_TRY(ctx, hipMemcpyAsync(bgr, ctx->d_display, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
     return PTMI_OK;
 }
 
@@ -622,12 +912,31 @@ int ptmi_read_statistics(ptmi_ctx* ctx, uint32_t* depths, uint32_t* bbx, uint32_
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_statistics before ptmi_initialize_memory");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t nd = ctx->cfg.ray_max_depth + 1;
-    if (depths) HIP_TRY(ctx, hipMemcpyAsync(depths, ctx->d_hist, nd * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (bbx) HIP_TRY(ctx, hipMemcpyAsync(bbx, ctx->d_hist + nd, PTMI_MAX_INTERSECTION_NUMBER * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (tri) HIP_TRY(ctx, hipMemcpyAsync(tri, ctx->d_hist + nd + PTMI_MAX_INTERSECTION_NUMBER, PTMI_MAX_INTERSECTION_NUMBER * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t words = (size_t)nd + 2 * PTMI_MAX_INTERSECTION_NUMBER;
+    std::vector<uint32_t> sum(words, 0u), part(words);
+    for (DeviceState& d : ctx->dev) {  // histograms are integer sums over the devices
+        ON_DEVICE(ctx, d);
+        HIP_TRY(ctx, hipMemcpyAsync(part.data(), d.d_hist, words * 4, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        for (size_t i = 0; i < words; i++) sum[i] += part[i];
+    }
+    if (depths) std::memcpy(depths, sum.data(), nd * 4);
+    if (bbx) std::memcpy(bbx, sum.data() + nd, PTMI_MAX_INTERSECTION_NUMBER * 4);
+    if (tri) std::memcpy(tri, sum.data() + nd + PTMI_MAX_INTERSECTION_NUMBER, PTMI_MAX_INTERSECTION_NUMBER * 4);
+    return PTMI_OK;
+}
+
+static int read_counter_block(ptmi_ctx* ctx, unsigned long long* total)
+{
+    for (int i = 0; i < C_COUNT; i++) total[i] = 0;
+    for (DeviceState& d : ctx->dev) {
+        ON_DEVICE(ctx, d);
+        unsigned long long h[C_COUNT];
+        HIP_TRY(ctx, hipMemcpyAsync(h, d.d_counters, sizeof h, hipMemcpyDeviceToHost, d.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        for (int i = 0; i < C_COUNT; i++) total[i] += h[i];
+    }
     return PTMI_OK;
 }
 
@@ -635,10 +944,8 @@ int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out)
 {
     if (!ctx || !out) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_get_counters before ptmi_initialize_memory");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long h[C_COUNT];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = read_counter_block(ctx, h)) return rc;
     out->paths = h[C_PATHS]; out->segments = h[C_SEGMENTS]; out->surface_hits = h[C_HITS];
     out->shadow_rays = h[C_SHADOW]; out->box_tests = h[C_BBX]; out->triangle_tests = h[C_TRI];
     return PTMI_OK;
@@ -648,10 +955,8 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
 {
     if (!ctx || !out) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_get_scheduler_stats before ptmi_initialize_memory");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long h[C_COUNT];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = read_counter_block(ctx, h)) return rc;
     out->trips_node = h[C_TRIPS_I]; out->lanes_node = h[C_LANES_I];
     out->trips_triangle = h[C_TRIPS_T]; out->lanes_triangle = h[C_LANES_T];
     out->trips_path = h[C_TRIPS_P]; out->lanes_path = h[C_LANES_P];
@@ -661,12 +966,17 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
 int ptmi_kernel_time(ptmi_ctx* ctx, double* total_ms, uint32_t* n_launches)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = fold_events(ctx)) return rc;
-    if (total_ms) *total_ms = ctx->kernel_ms;
-    if (n_launches) *n_launches = ctx->kernel_launches;
-    ctx->kernel_ms = 0;
-    ctx->kernel_launches = 0;
+    double ms = 0;
+    uint32_t n = 0;
+    for (DeviceState& d : ctx->dev) {  // summed over the devices: total / launches stays the average launch duration
+        if (int rc = fold_events(ctx, d)) return rc;
+        ms += d.kernel_ms;
+        n += d.kernel_launches;
+        d.kernel_ms = 0;
+        d.kernel_launches = 0;
+    }
+    if (total_ms) *total_ms = ms;
+    if (n_launches) *n_launches = n;
     return PTMI_OK;
 }
 
@@ -674,8 +984,9 @@ int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_color, void** d_count)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_device_accumulators before ptmi_initialize_memory");
-    if (d_color) *d_color = ctx->ds.image_color;
-    if (d_count) *d_count = ctx->ds.image_ray_nb;
+    if (ctx->n_dev() != 1) return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_device_accumulators on a multi-device context (partial sums)");
+    if (d_color) *d_color = ctx->dev[0].ds.image_color;
+    if (d_count) *d_count = ctx->dev[0].ds.image_ray_nb;
     return PTMI_OK;
 }
 
@@ -683,8 +994,8 @@ int ptmi_device_variance(ptmi_ctx* ctx, void** d_image_v)
 {
     if (!ctx || !d_image_v) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_device_variance before ptmi_initialize_memory");
-    if (!ctx->ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
-    *d_image_v = ctx->ds.image_v;
+    if (!ctx->dev[0].ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
+    *d_image_v = ctx->dev[0].ds.image_v;
     return PTMI_OK;
 }
 
@@ -692,11 +1003,23 @@ int ptmi_read_variance(ptmi_ctx* ctx, float* image_v)
 {
     if (!ctx || !image_v) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_variance before ptmi_initialize_memory");
-    if (!ctx->ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t npix = (size_t)ctx->cfg.image_width * ctx->cfg.image_height;
-    HIP_TRY(ctx, hipMemcpyAsync(image_v, ctx->ds.image_v, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DeviceState& d = ctx->dev[0];
+    if (!d.ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
+    ON_DEVICE(ctx, d);
+    HIP_TRY(ctx, hipMemcpyAsync(image_v, d.ds.image_v, ctx->npix() * 16, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    return PTMI_OK;
+}
+
+int ptmi_write_variance(ptmi_ctx* ctx, const float* image_v)
+{
+    if (!ctx || !image_v) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_write_variance before ptmi_initialize_memory");
+    DeviceState& d = ctx->dev[0];
+    if (!d.ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
+    ON_DEVICE(ctx, d);
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    HIP_TRY(ctx, hipMemcpy(d.ds.image_v, image_v, ctx->npix() * 16, hipMemcpyHostToDevice));
     return PTMI_OK;
 }
 
@@ -704,26 +1027,36 @@ int ptmi_bind_accumulators(ptmi_ctx* ctx, void* d_color, void* d_count)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_bind_accumulators before ptmi_initialize_memory");
+    if (ctx->n_dev() != 1) return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_bind_accumulators on a multi-device context");
     if ((d_color == nullptr) != (d_count == nullptr))
         return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "bind both accumulators or neither");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->ds.image_color = d_color ? (float*)d_color : ctx->d_color;
-    ctx->ds.image_ray_nb = d_count ? (float*)d_count : ctx->d_count;
+    DeviceState& d = ctx->dev[0];
+    ON_DEVICE(ctx, d);
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    d.ds.image_color = d_color ? (float*)d_color : d.d_color;
+    d.ds.image_ray_nb = d_count ? (float*)d_count : d.d_count;
     ctx->accum_bound = d_color != nullptr;
-    HIP_TRY(ctx, hipMemcpy(ctx->d_scene, &ctx->ds, sizeof(DScene), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
     return PTMI_OK;
 }
 
 void ptmi_release(ptmi_ctx* ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (auto& ev : ctx->pending_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     free_scene_memory(ctx);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (auto& r : ctx->seen_host)
+        if (r.registered) (void)hipHostUnregister(r.p);
+    if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);
+    for (DeviceState& d : ctx->dev) {
+        (void)hipSetDevice(d.device);
+        for (auto& ev : d.pending_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto& ev : d.free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++)
+            if (d.snapshot_ready[k]) (void)hipEventDestroy(d.snapshot_ready[k]);
+        if (d.peer_copied) (void)hipEventDestroy(d.peer_copied);
+        if (d.own_stream) (void)hipStreamDestroy(d.own_stream);
+        if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
+    }
     delete ctx;
 }
 

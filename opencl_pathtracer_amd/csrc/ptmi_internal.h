@@ -132,20 +132,26 @@ struct DScene {
 };
 
 // kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)
-int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, void* stream, std::string* err);
+// iteration ids of a launch: first_iteration + k * iteration_stride, k < n_iterations
+int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t iteration_stride, void* stream,
+                  std::string* err);
 
 // kernel_wavefront.hip: persistent wavefront state machine (default)
 // stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30)
 int wavefront_resident_blocks(int device, uint32_t stack_levels);
 // scene_in_device_memory = a device copy of `sc` (the kernel takes only the hot fields by value)
 int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
-                            uint32_t n_iterations, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
+                            uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
                             bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err);
 // stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself)
 
 // display.hip: accumulators -> padded B,G,R scanlines (the reference's ConvertRGBAToBMPBuffer), on the device
 int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint8_t* out, uint32_t width, uint32_t height,
                        uint32_t row_stride, void* stream, std::string* err);
+
+// display.hip: out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...  in this fixed order (the accumulators of the devices
+// that shared a render, summed on the first one: ptmi_read_image / ptmi_read_snapshot); n_parts <= PTMI_MAX_DEVICES
+int launch_sum_images(float* out, const float* const* parts, uint32_t n_parts, size_t n_floats, void* stream, std::string* err);
 
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
 constexpr uint32_t kMaxIterationsPerLaunch = 16;

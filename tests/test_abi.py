@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built):
                          check=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "ptmi_" in l and "_Z" not in l}
     assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
-    assert lib.ptmi_abi_version() == 1
+    assert lib.ptmi_abi_version() == 2
 
 
 def test_headers_compile_as_c_and_cpp(tmp_path):
@@ -52,7 +52,7 @@ def test_numpy_dtypes_match_the_header():
     assert S.Triangle.fields["materialWithPositiveNormalIndex"][1] == 320
     assert S.Node.fields["son1Id"][1] == 140 and S.Node.fields["isLeaf"][1] == 152
     assert S.Material.fields["opacity"][1] == 24 and S.Material.fields["isSimpleColor"][1] == 36
-    assert C.sizeof(backend.Config) == 36 and C.sizeof(backend.Counters) == 48
+    assert C.sizeof(backend.Config) == 104 and C.sizeof(backend.Counters) == 48
 
 
 def test_argument_validation_needs_no_gpu(built):

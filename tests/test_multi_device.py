@@ -1,0 +1,158 @@
+"""Multi-GPU inside libptmi (SURVEY 8e behind the boundary): the iteration ids of every ptmi_render call are dealt to the
+devices of the context modulo the device count, each device renders the full image for its ids on its own scene
+replica, and ptmi_read_image / ptmi_read_snapshot sum the partial accumulators on devices[0] in device order.
+
+CPU part: the id arithmetic (ptmi_device_share).  GPU part: on a one-GPU box the same device listed two or three
+times runs the whole multi-device control flow (replicas, per-device streams, snapshots, peer copies, the sum kernel);
+its image must equal the single-context one up to the order of the float additions, its counts, histograms and
+counters exactly.  The snapshot ring (launches of the next images queued while image k is read back) is checked
+against the blocking loop image by image.
+"""
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+from opencl_pathtracer_amd import Backend, PtmiError, render_scene, structs as S
+from opencl_pathtracer_amd.backend import device_share
+
+
+@pytest.mark.parametrize("first,n,G", [(0, 16, 1), (0, 16, 2), (5, 1, 4), (7, 13, 3), (0, 4096, 8), (3, 2, 8), (10, 0, 4),
+                                        (4294967000, 200, 7)])
+def test_device_shares_partition_the_ids(first, n, G, built):
+    ids = []
+    for k in range(G):
+        f, m = device_share(first, n, k, G)
+        mine = [f + j * G for j in range(m)]
+        assert all(i % G == k and first <= i < first + n for i in mine)
+        ids += mine
+    assert sorted(ids) == list(range(first, first + n))
+    sizes = [device_share(first, n, k, G)[1] for k in range(G)]
+    assert max(sizes) - min(sizes) <= 1  # balanced to one id
+
+
+def test_device_share_single_calls_rotate(built):
+    """The reference's loop renders one image per call (OpenCL.cpp:76-89): call i must land on device i mod G."""
+    for G in (2, 3, 8):
+        for i in range(20):
+            owners = [k for k in range(G) if device_share(i, 1, k, G)[1] == 1]
+            assert owners == [i % G]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel_flags", [0, 2])
+@pytest.mark.parametrize("G", [2, 3])
+def test_same_device_listed_several_times_equals_single_context(G, kernel_flags, scene_factory):
+    name, sampler, w, h, d = cases.CASES["matmix_96x96_d8"]
+    sc = scene_factory(name, w, h)
+    spp = 11  # not a multiple of G: shares of different sizes
+    one, one_n, (dep, bbx, tri), counters = render_scene(sc, w, h, d, spp, flags=kernel_flags)
+    m, m_n, (m_dep, m_bbx, m_tri), m_counters = render_scene(sc, w, h, d, spp, flags=kernel_flags, devices=[0] * G)
+    assert np.array_equal(m_n, one_n) and m_counters == counters
+    assert np.array_equal(m_dep, dep) and np.array_equal(m_bbx, bbx) and np.array_equal(m_tri, tri)
+    assert (cases.rms_per_channel(m, m_n, one, one_n) <= 1e-6).all()
+    assert np.allclose(m, one, rtol=2e-6, atol=1e-6)
+    # and the parts are what the id arithmetic says: device k's share rendered alone, summed in device order, bit for bit
+    parts = []
+    for k in range(G):
+        f, n = device_share(0, spp, k, G)
+        be = Backend().setup_context(w, h, d, sc.lightsSize, sampler, flags=kernel_flags)
+        be.initialize_memory(sc)
+        for j in range(n):  # ids f, f + G, ...: one call each on a single-device context
+            be.render(f + j * G, 1)
+        parts.append(be.read_image())
+        be.release()
+    total = parts[0][0].copy()
+    for c, _ in parts[1:]:
+        total = total + c
+    assert np.array_equal(total.view(np.uint32), m.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_one_image_per_call_over_two_devices(scene_factory):
+    """The reference's call pattern (render(i, 1) per image) over a two-device context, readbacks in between."""
+    w, h, d = 64, 48, 4
+    sc = scene_factory("cornell", w, h)
+    single = Backend().setup_context(w, h, d, sc.lightsSize)
+    single.initialize_memory(sc)
+    multi = Backend().setup_context(w, h, d, sc.lightsSize, devices=[0, 0])
+    multi.initialize_memory(sc)
+    for i in range(5):
+        single.render(i, 1)
+        multi.render(i, 1)
+        a, an = single.read_image()
+        b, bn = multi.read_image()
+        assert np.array_equal(an, bn) and float(an.max()) == i + 1
+        assert np.allclose(a, b, rtol=2e-6, atol=1e-6)
+    assert single.counters() == multi.counters()
+    bgr_s, bgr_m = single.read_display(), multi.read_display()
+    assert np.abs(bgr_s.astype(int) - bgr_m.astype(int)).max() <= 1  # quantised after two summation orders
+    with pytest.raises(PtmiError):
+        multi.device_accumulators()  # partial sums are not handed out
+    with pytest.raises(PtmiError):
+        multi.set_stream(0)
+    single.release()
+    multi.release()
+
+
+@pytest.mark.gpu
+def test_super_sampling_needs_one_device(built):
+    with pytest.raises(PtmiError) as e:
+        Backend().setup_context(8, 8, 2, 0, super_sampling=True, devices=[0, 0])
+    assert e.value.code == -7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_snapshot_ring_equals_blocking_loop(devices, scene_factory):
+    """Launches of images k+1, k+2 are queued BEFORE image k is read back: every snapshot still holds exactly images 0..k."""
+    w, h, d = 96, 64, 6
+    sc = scene_factory("tris20k", w, h)
+    n_img, lookahead = 7, 2
+    slots = lookahead + 1
+    blocking = Backend().setup_context(w, h, d, sc.lightsSize, devices=devices)
+    blocking.initialize_memory(sc)
+    expect = []
+    for i in range(n_img):
+        blocking.render(i, 1)
+        blocking.synchronize()
+        c, n = blocking.read_image()
+        expect.append((c.copy(), n.copy()))
+    blocking.release()
+
+    be = Backend().setup_context(w, h, d, sc.lightsSize, devices=devices)
+    be.initialize_memory(sc)
+    out = (np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32))  # reused: page-locked from the second read on
+    queued = 0
+    for i in range(n_img):
+        while queued < n_img and queued <= i + lookahead:
+            be.render(queued, 1)
+            be.snapshot(queued % slots)
+            queued += 1
+        c, n = be.read_snapshot(i % slots, out=out)
+        assert np.array_equal(n, expect[i][1]), i
+        assert np.array_equal(c.view(np.uint32), expect[i][0].view(np.uint32)), i
+    with pytest.raises(PtmiError):
+        be.read_snapshot(slots + 1)  # never filled
+    with pytest.raises(PtmiError):
+        be.snapshot(99)
+    be.release()
+
+
+@pytest.mark.gpu
+def test_multi_device_bit_exact_parts_vs_oracle(scene_factory):
+    """Each device's share is the oracle's image of exactly those iteration ids (the samples are a pure function of
+    pixel and id, header.cl:255-264): two devices, ids 0,2,4 and 1,3,5."""
+    w, h, d = 64, 48, 4
+    sc = scene_factory("cornell", w, h)
+    parts = []
+    for k in range(2):
+        acc = np.zeros((h, w, 4), np.float32)
+        for j in range(3):
+            c, _, _, _ = O.oracle_render(sc, w, h, d, 1, first_iteration=k + 2 * j)
+            acc = acc + c
+        parts.append(acc)
+    expect = parts[0] + parts[1]
+    color, count, _, _ = render_scene(sc, w, h, d, 6, devices=[0, 0])
+    assert float(count.min()) == 6.0 == float(count.max())
+    assert np.array_equal(color.view(np.uint32), expect.view(np.uint32))

@@ -123,6 +123,47 @@ def test_degenerate_trees_and_big_leaves(kernel, scene_factory):
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
+def test_leaf_without_triangles_next_to_a_leaf(kernel, scene_factory):
+    """A hand-made tree the product builder never emits: a leaf with nbTriangles == 0 whose box is NOT flagged isEmpty,
+    sibling of an ordinary leaf.  The reference descends into it (its leaf loop runs zero times, FullKernel.cl:638-646)
+    and pops the sibling; the device layout stores such a leaf as an empty child - same image, same counters - instead of
+    letting the wavefront kernel pop a leaf reference where it expects an inner node."""
+    import copy
+    base = scene_factory("cornell", 64, 48)
+    sc = copy.copy(base)
+    bvh = base.bvh
+    leaf = bvh["isLeaf"] != 0
+    # every inner node both of whose children are leaves gets its second child replaced by a new inner node
+    # (empty leaf E, the old leaf B), E carrying B's box: rays meet E as the near child or as the far one
+    parents = [i for i in range(len(bvh)) if not leaf[i] and leaf[bvh["son1Id"][i]] and leaf[bvh["son2Id"][i]]]
+    assert parents
+    extra = np.zeros(2 * len(parents), dtype=S.Node)
+    new = np.frombuffer(bytearray(bvh.tobytes() + extra.tobytes()), dtype=S.Node)
+    for j, p in enumerate(parents):
+        y, e = len(bvh) + 2 * j, len(bvh) + 2 * j + 1
+        b = int(new["son2Id"][p])
+        new[y] = new[b]
+        new["isLeaf"][y] = 0
+        new["nbTriangles"][y] = 0
+        new["cutAxis"][y] = (int(new["cutAxis"][p]) + 1) % 3
+        new["son1Id"][y], new["son2Id"][y] = (e, b) if j % 2 == 0 else (b, e)
+        new[e] = new[b]
+        new["nbTriangles"][e] = 0
+        new["trianglesAABB"]["isEmpty"][e] = 0
+        new["son2Id"][p] = y
+    sc.bvh = new
+    sc.bvhMaxDepth = base.bvhMaxDepth + 1
+    color, count, (dep, bbx, tri), counters = render_scene(sc, 64, 48, 4, 4, flags=KERNELS[kernel])
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 64, 48, 4, 4)
+    assert counters == totals and counters["box_tests"] > O.oracle_render(base, 64, 48, 4, 4)[3]["box_tests"]
+    assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
+    # the extra nodes change the work, not the picture
+    plain, _, _, _ = render_scene(base, 64, 48, 4, 4, flags=KERNELS[kernel])
+    assert np.array_equal(color.view(np.uint32), plain.view(np.uint32))
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 def test_unconventional_w_components(kernel, scene_factory):
     """OpenCL's dot/normalize are 4-component: scenes whose w lanes break the importer's conventions (points
     w=1, N.w=1, normals w=0) must still equal the reference algorithm, which the oracle evaluates literally."""

@@ -102,3 +102,61 @@ def test_shim_end_to_end_matches_oracle(name, w, h, d, sampler, n, driver, tmp_p
     o_color, o_count, (o_dep, o_bbx, o_tri), _ = O.oracle_render(ref, w, h, d, n, sampler=sampler)
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
     assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+
+
+# ---- the reference's own orchestration over the shim ----------------------------------------------------------------
+# oracle/_ref/ref_main_driver (oracle/Makefile: ref-main) = the reference's Controleur/PathTracer.cpp and
+# PathTracer_Importer.cpp compiled UNMODIFIED + csrc/PathTracer_HIP.cpp built against the reference's own headers +
+# libptmi.so.  PathTracer_Main (PathTracer.cpp:25-110) is called with the ten arguments of Maya/RayTracer.cpp:121.
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "ref_main_driver")
+
+
+def read_painted(path, w, h):
+    raw = open(path, "rb").read()
+    calls, pw, ph = struct.unpack_from("<3I", raw, 0)
+    assert (pw, ph) == (w, h)
+    color = np.frombuffer(raw, np.float32, w * h * 4, 12).reshape(h, w, 4)
+    count = np.frombuffer(raw, np.float32, w * h, 12 + w * h * 16).reshape(h, w)
+    return calls, color, count
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="oracle/_ref/ref_main_driver not built (needs the reference tree)")
+def test_reference_orchestration_links_and_reports_a_missing_device(tmp_path):
+    """On a box without a GPU PathTracer_Main must catch the backend's std::runtime_error (PathTracer.cpp:99-107), log
+    it and return false - not crash, not fall back to a CPU path."""
+    from opencl_pathtracer_amd import backend
+    if backend.load_library().ptmi_device_count() > 0:
+        pytest.skip("a GPU is present: see test_reference_orchestration_renders")
+    sc = scenes.cornell_box(32, 24)
+    scene_file, out_file = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
+    dump_scene(scene_file, sc, 32, 24, 3, S.JITTERED, 2)
+    r = subprocess.run([REF_MAIN, scene_file, out_file], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "BUILDING BVH" in r.stdout and "SETTING OPENCL CONTEXT" in r.stdout  # the reference's own section banners
+    assert "ERROR : OpenCL_SetupContext failed" in r.stdout and "no HIP device" in r.stdout
+    assert "PathTracer_Main returned false" in r.stdout and not os.path.exists(out_file)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="oracle/_ref/ref_main_driver not built (needs the reference tree)")
+@pytest.mark.parametrize("env", [{}, {"PTMI_DEVICES": "0,0", "PTMI_LOOKAHEAD": "3"}, {"PTMI_LOOKAHEAD": "0"}])
+def test_reference_orchestration_renders(env, tmp_path):
+    """PathTracer_Main -> BVH_Create -> OpenCL_SetupContext / InitializeMemory / RunKernel of the shim -> libptmi -> HIP
+    kernels; the image the reference's window is handed after the last iteration equals the oracle's."""
+    name, w, h, d, n = "cornell", 64, 48, 4, 6
+    sc = scenes.build(name, w, h)
+    scene_file, out_file = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
+    dump_scene(scene_file, sc, w, h, d, S.JITTERED, n)
+    r = subprocess.run([REF_MAIN, scene_file, out_file], capture_output=True, text=True, cwd=str(tmp_path),
+                       env={**os.environ, **env})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PathTracer_Main returned true" in r.stdout and "Number of shot rays" in r.stdout  # PathTracer_ComputeStatistics ran
+    calls, color, count = read_painted(out_file, w, h)
+    assert calls == n
+    ref = bvh_create(scenes.build(name, w, h))
+    o_color, o_count, _, _ = O.oracle_render(ref, w, h, d, n)
+    assert np.array_equal(count, o_count)
+    if env.get("PTMI_DEVICES"):  # two partial sums: another order of the float additions
+        assert np.allclose(color, o_color, rtol=2e-6, atol=1e-6)
+    else:
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
