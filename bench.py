@@ -2,19 +2,23 @@
 """bench.py - the reference's headline metric on MI355X.
 
 Metric (BASELINE.json): Msamples/s, sample = one path segment = one closest-hit query
-(BVH_IntersectRay call; "paths x bounces"), at 1920x1080.  Workload at every N: BASELINE.json
+(BVH_IntersectRay call; "paths x bounces"), at 1920x1080.  Default workload at every N: BASELINE.json
 configs[2] -- the synthetic 1M-random-triangle scene, 1920x1080, depth 10, JITTERED, one point light
 (generator pinned in opencl_pathtracer_amd/scenes.py, BVH from the bit-compatible builder).
 A "step" = one pass of the integrator over one batch = --spp-per-step iterations (samples per pixel)
-of the full image.  Inputs (scene + accumulators) are resident in HBM before the timed region.
+of the full image.  Inputs (scene + accumulators) are resident in HBM before the timed region; the timed
+region ends with the framebuffer on the host of rank 0 (one readback).
 
-Multi-GPU (torchrun, one rank per GPU): iteration ids are partitioned over ranks (weak scaling: each
-rank renders --spp-per-step ids per step on a full scene replica, no data-path exchange) and ONE
-RCCL reduce of the fused float[5*W*H] accumulators onto rank 0 closes the timed region.
+Multi-GPU (torchrun, one rank per GPU): iteration ids are partitioned over ranks, each rank renders its ids
+on a full scene replica with no data-path exchange, and ONE RCCL reduce of the fused float[5*W*H] accumulators
+onto rank 0 closes the timed region.  Weak scaling by default (every rank renders --spp-per-step ids per step);
+--strong / --total-spp fix the job instead (BASELINE configs[3]: 4096 spp split over the ranks).
 
-Prints ONE JSON line on rank 0.  Extra objects: "roofline" (HBM, algorithmic bytes from the kernel's
-own exact counters / launch time from HIP events on the kernel's stream) and, at N=1, "cpu_baseline"
-(the CPU oracle = scalar port of the reference kernel, timed on the host cores on one iteration).
+Prints ONE JSON line on rank 0.  Extra objects: "roofline" (HBM on SURVEY 8d's algorithmic bytes, plus the measured
+memory-side traffic and the ceilings that actually bind, from the PMC passes committed under profiles/), at N=1
+"cpu_baseline" (the CPU oracle = scalar port of the reference kernel, timed on the host cores on a bounded sample)
+and "boundary" (the same integrator driven the way the reference drives its backend: one image per launch, a
+readback and a callback after every image, OpenCL.cpp:76-107).
 """
 import argparse
 import json
@@ -25,12 +29,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+# tools/microbench/record_fetch.hip on MI355X (profiles/r01_ab_late_round.txt): random 64-byte records, per-lane 4 x dwordx4,
+# G records/s chip-wide when the set sits in the L2s / in the Infinity Cache
+RECORD_FETCH_L2 = 214.5e9
+RECORD_FETCH_MALL = 56.8e9
 
 
 def algorithmic_bytes(c, n_pixels, n_flush):
     """32 B per box test, 48 B per triangle test, 96 B per surface hit, 40 B per pixel per
-    accumulator flush (texel reads: none in this workload)."""
+    accumulator flush (texel reads: none in the BASELINE workloads that are timed here)."""
     return 32 * c["box_tests"] + 48 * c["triangle_tests"] + 96 * c["surface_hits"] + 40 * n_pixels * n_flush
 
 
@@ -39,7 +49,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=16,
+                    help="iterations per step: per GPU (weak scaling, default) or for the whole job (--strong)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --spp-per-step ids per step are split over the ranks")
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="strong scaling of a fixed job (BASELINE configs[3]: 4096): steps = total / spp-per-step, no warm-up")
     ap.add_argument("--scene", default="tris1m")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -47,12 +61,14 @@ def main():
     ap.add_argument("--kernel", choices=["wavefront", "megakernel"], default="wavefront")
     ap.add_argument("--scheduler-stats", action="store_true", help="also report wave-scheduler statistics (costs ~1 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the reference-style per-image loop (N=1 only)")
     ap.add_argument("--no-histograms", action="store_true",
                     help="skip the reference's three per-path statistics atomics (FullKernel.cl:1319-1331); default: keep them")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo is a rehearsal of the N>1 control flow on a one-GPU box "
                          "(all ranks share GPU 0, accumulators are reduced through host memory)")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of iteration 0 the CPU baseline renders (0 = auto)")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="image rows the CPU baseline renders (0 = auto)")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="iterations the CPU baseline renders (0 = auto: 10-30 s of CPU work)")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,7 +76,7 @@ def main():
     import torch.distributed as dist
     import opencl_pathtracer_amd as pt
     from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS, FLAG_MEGAKERNEL, FLAG_SCHEDULER_STATS
-    from opencl_pathtracer_amd.distributed import FusedAccumulators
+    from opencl_pathtracer_amd.distributed import FusedAccumulators, shard_iterations
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,13 +96,16 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     W, H, D, B = args.width, args.height, args.depth, args.spp_per_step
+    strong = args.strong or args.total_spp > 0
+    if args.total_spp > 0:
+        args.steps, args.warmup = max(1, args.total_spp // B), 0
     t0 = time.time()
     scene = pt.bvh_create(pt.scenes.build(args.scene, W, H))
     t_scene = time.time() - t0
 
-    be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=local_rank,
-                                    flags=(FLAG_NO_HISTOGRAMS if args.no_histograms else 0) | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0)
-                                    | (FLAG_SCHEDULER_STATS if args.scheduler_stats else 0))
+    flags = ((FLAG_NO_HISTOGRAMS if args.no_histograms else 0) | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0)
+             | (FLAG_SCHEDULER_STATS if args.scheduler_stats else 0))
+    be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=local_rank, flags=flags)
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)
     fb.bind(be)
@@ -95,16 +114,21 @@ def main():
     stream = torch.cuda.Stream(device)
     assert stream.cuda_stream != 0
     be.set_stream(stream.cuda_stream)
+    host_image = torch.empty(5 * W * H, dtype=torch.float32, pin_memory=True) if rank == 0 else None
 
     def step(s):
-        # global step s covers iteration ids [s*B*world, (s+1)*B*world); this rank takes its block of B
-        be.render((s * world + rank) * B, B)
+        if strong:  # global step s covers ids [s*B, (s+1)*B): this rank's contiguous share of them
+            first, n = shard_iterations(s * B, B, rank, world)
+        else:       # weak: ids [s*B*world, (s+1)*B*world), a block of B per rank
+            first, n = (s * world + rank) * B, B
+        if n:
+            be.render(first, n)
 
     torch.cuda.synchronize(device)
     torch.cuda.set_stream(stream)
     for s in range(args.warmup):
         step(s)
-    if world > 1 and args.backend == "nccl" and args.warmup > 0:
+    if world > 1 and args.backend == "nccl":
         # warm the collective too (RCCL sets up its channels for a message size on first use): same size, same
         # stream, scratch data - the accumulators are only reduced once, inside the timed region
         scratch = torch.zeros_like(fb.buffer)
@@ -124,7 +148,9 @@ def main():
         dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
         fb.buffer.copy_(host)
     else:
-        fb.reduce_to(0)  # the one collective of a sharded render: RCCL reduce over xGMI (no-op at N=1)
+        fb.reduce_to(0, ordered=True)  # same stream as the launches; the one collective of a sharded render: RCCL reduce over xGMI (no-op at N=1)
+    if rank == 0:
+        host_image.copy_(fb.buffer, non_blocking=True)  # t_render ends with the framebuffer on the host
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
@@ -144,89 +170,192 @@ def main():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total = dict(zip(sorted(delta), [int(x) for x in cnt.tolist()]))
+    be.release()
 
     if rank == 0:
-        color, count = fb.images()
-        expected = float((args.warmup + args.steps) * B * world)
-        assert np.isfinite(color).all() and float(count.min()) == expected == float(count.max()), \
-            f"sample count {count.min()}..{count.max()} != {expected}"
         n_pix = W * H
+        color = host_image[: 4 * n_pix].view(H, W, 4).numpy()
+        count = host_image[4 * n_pix:].view(H, W).numpy()
+        spp_done = (args.warmup + args.steps) * B * (1 if strong else world)
+        assert np.isfinite(color).all() and float(count.min()) == float(spp_done) == float(count.max()), \
+            f"sample count {count.min()}..{count.max()} != {spp_done}"
         b_alg = algorithmic_bytes(delta, n_pix, launches)
         avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = b_alg / max(launches, 1) / avg_launch_s / 1e9
-        traffic = committed_traffic(args, W, H, D, B)
+        records_per_launch = (delta["box_tests"] / 2 + delta["triangle_tests"]) / max(launches, 1)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "render_wavefront_kernel" if args.kernel == "wavefront" else "render_kernel",
+                "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+                "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
+                "box_tests_per_path": delta["box_tests"] / max(delta["paths"], 1),
+                "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1),
+                "record_fetches_per_s": records_per_launch / avg_launch_s,
+                "note": "achieved = SURVEY 8d ALGORITHMIC bytes (a model of what the traversal must read: 32 B per box test, 48 B per "
+                        "triangle test ...) / launch time measured with HIP events on the kernel's stream.  Where the record array fits "
+                        "the L2s + Infinity Cache this stream never reaches HBM and the figure may exceed the HBM peak: 'hbm_measured' "
+                        "is the memory-side traffic of the PMC passes and 'binding' the ceilings the kernel actually runs into"}
+        pmc = committed_pmc(args, W, H, D, B)
+        if pmc:
+            roof.update(binding_ceilings(pmc, avg_launch_s, records_per_launch))
         out = {
             "metric": "Msamples/s (paths x bounces) at 1920x1080",
             "value": total["segments"] / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload_name(args.scene)}: {len(scene.triangulation)} triangles "
                                    f"({len(scene.bvh)} BVH nodes, depth {scene.bvhMaxDepth}), {W}x{H}, "
                                    f"ray depth {D}, JITTERED, {scene.lightsSize} light(s)",
-                       "spp_per_step_per_gpu": B, "spp_total": args.steps * B * world,
+                       "spp_per_step": B if strong else B * world, "spp_per_step_per_gpu": B / world if strong else B,
+                       "spp_total": args.steps * B * (1 if strong else world),
                        "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU",
+                       "timed_region": "launches + RCCL reduce + one framebuffer readback to rank 0 (pinned host memory)",
                        "scene_build_s": round(t_scene, 2)},
             "Mpaths/s": total["paths"] / elapsed / 1e6,
             "Mshadow_rays/s": total["shadow_rays"] / elapsed / 1e6,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "render_wavefront_kernel" if args.kernel == "wavefront" else "render_kernel",
-                         "launches": launches,
-                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
-                         "box_tests_per_path": delta["box_tests"] / max(delta["paths"], 1),
-                         "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1),
-                         "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; a fraction above 1 means the record "
-                                 "stream is served by L2 + Infinity Cache (see traffic = measured HBM bytes per launch), "
-                                 "DESIGN.md 5 'What binds'"},
+            "roofline": roof,
         }
         if sched["trips_node"]:
             out["wave_scheduler"] = {k: round(sched["lanes_" + k] / (64.0 * sched["trips_" + k]), 3) if sched["trips_" + k] else None
                                      for k in ("node", "triangle", "path")}
             tot = sum(sched["trips_" + k] for k in ("node", "triangle", "path"))
             out["wave_scheduler"]["trip_share"] = {k: round(sched["trips_" + k] / tot, 3) for k in ("node", "triangle", "path")}
+        if world == 1 and not args.no_boundary:
+            out["boundary"] = boundary_loop(pt, scene, W, H, D, local_rank, flags, out["value"])
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, D, args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, D, args.cpu_rows, args.cpu_spp)
         print(json.dumps(out), flush=True)
 
-    be.release()
     if world > 1:
         dist.destroy_process_group()
 
 
 def workload_name(scene):
     return {"tris1m": "BASELINE configs[2]: synthetic random-triangle scene (numpy MT19937 seed 12345)",
-            "cornell": "BASELINE configs[1]: Cornell box (point light under a lamp quad)",
+            "tris4m": "HBM-regime variant of configs[2]: 4M random triangles, 427 MB of records (> the 256 MiB Infinity Cache)",
+            "cornell": "BASELINE configs[0]/[1]: Cornell box (point light under a lamp quad)",
             "matmix": "BASELINE configs[4] stand-in: textured multi-material scene (no Maya assets exist)"}.get(scene, scene)
 
 
-def committed_traffic(args, W, H, D, B):
-    """roofline.traffic: memory-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled as the gfx950 note of
-    MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads).  Only quoted for the configuration it was
-    measured on; None otherwise (bench.py itself cannot read PMC counters)."""
-    path = os.path.join(ROOT, "profiles", "r01_wavefront_pmc.json")
-    if not os.path.exists(path) or (args.scene, W, H, D, B, args.kernel) != ("tris1m", 1920, 1080, 10, 16, "wavefront"):
+def committed_pmc(args, W, H, D, B):
+    """Per-launch means of the rocprofv3 --pmc passes of THIS command line (tools/profile_round.sh: one counter group per
+    run, summarised by tools/summarize_pmc.py), committed as profiles/r02_pmc_<scene>.json.  bench.py itself cannot read
+    PMC counters; the file is only used for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.scene}.json")
+    if not os.path.exists(path) or (W, H, D, B, args.kernel) != (1920, 1080, 10, 16, "wavefront"):
         return None
     pmc = json.load(open(path))
-    return (2.0 * pmc["FETCH_SIZE"]["per_launch_mean"] + pmc["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+    pmc["_path"] = os.path.relpath(path, ROOT)
+    return pmc
 
 
-def cpu_baseline(scene, W, H, D, rows):
+def binding_ceilings(pmc, launch_s, records_per_launch):
+    """traffic = memory-side bytes per launch (FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes for
+    16-byte-per-lane loads, plus WRITE_SIZE), and the three ceilings the kernel runs into, each as a fraction <= 1."""
+    v = lambda k: pmc[k]["per_launch_mean"] if k in pmc else None
+    out = {"traffic_source": pmc["_path"] + " (PMC passes of this command, committed; not measured in this run)"}
+    if v("FETCH_SIZE") is not None and v("WRITE_SIZE") is not None:
+        traffic = (2.0 * v("FETCH_SIZE") + v("WRITE_SIZE")) * 1024.0
+        out["traffic"] = traffic
+        out["hbm_measured"] = {"achieved": traffic / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": traffic / launch_s / 1e9 / HBM_PEAK_GBS}
+    binding = {}
+    if v("SQ_INSTS_VALU") is not None:
+        # a wave64 VALU instruction holds its SIMD's issue port for 4 cycles; cycles of the launch from GRBM_GUI_ACTIVE
+        # (summed over the 8 XCDs) where collected, else at the 2.4 GHz maximum clock
+        cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
+        binding["valu_issue"] = {"achieved": v("SQ_INSTS_VALU") * 4.0 / N_SIMD, "peak": cycles, "unit": "cycles per SIMD per launch",
+                                 "frac": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles}
+    if v("TCC_HIT_sum") is not None and v("TCC_MISS_sum") is not None:
+        req = (v("TCC_HIT_sum") + v("TCC_MISS_sum")) * 64.0
+        binding["l2_requests"] = {"achieved": req / launch_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                                  "frac": req / launch_s / 1e9 / L2_PEAK_GBS,
+                                  "hit_rate": v("TCC_HIT_sum") / (v("TCC_HIT_sum") + v("TCC_MISS_sum"))}
+        # record-fetch ceiling for this scene's split between L2 hits and lines from the Infinity Cache / HBM
+        # (tools/microbench/record_fetch): time = hits / rate_L2 + misses / rate_MALL, in records of 64 bytes
+        hit = v("TCC_HIT_sum") / (v("TCC_HIT_sum") + v("TCC_MISS_sum"))
+        t_min = records_per_launch * (hit / RECORD_FETCH_L2 + (1.0 - hit) / RECORD_FETCH_MALL)
+        binding["record_fetch"] = {"achieved": records_per_launch / launch_s / 1e9, "peak": records_per_launch / t_min / 1e9,
+                                   "unit": "G records/s", "frac": t_min / launch_s}
+    if v("SQ_WAVE_CYCLES") is not None and v("SQ_WAIT_ANY") is not None:
+        binding["wave_cycles"] = {"waiting": v("SQ_WAIT_ANY") / v("SQ_WAVE_CYCLES"),
+                                  "issue_stalled": (v("SQ_WAIT_INST_ANY") or 0.0) / v("SQ_WAVE_CYCLES"),
+                                  "issuing": (v("SQ_ACTIVE_INST_ANY") or 0.0) / v("SQ_WAVE_CYCLES")}
+    if binding:
+        binding["binds"] = max((k for k in binding if "frac" in binding[k]), key=lambda k: binding[k]["frac"])
+        out["binding"] = binding
+    return out
+
+
+def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
+    """The integrator driven the way the reference drives its backend (OpenCL.cpp:76-107): ONE image per launch, the
+    framebuffer read back into the viewer's buffers and a callback after EVERY image - through the same C ABI calls
+    csrc/PathTracer_HIP.cpp makes.  Three variants: the reference's blocking sequence (launch, wait, read, callback),
+    the shim's default (launches of the next two images queued while image k crosses the bus: ptmi_snapshot /
+    ptmi_read_snapshot into page-locked buffers), and 16 images per launch and callback (PTMI_IMAGES_PER_LAUNCH=16)."""
+    import numpy as np
+    be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=device, flags=flags)
+    be.initialize_memory(scene)
+    out = (np.empty((H, W, 4), np.float32), np.empty((H, W), np.float32))
+    be.pin_host_buffer(out[0])
+    be.pin_host_buffer(out[1])
+    calls = [0]
+
+    def callback():
+        calls[0] += 1
+
+    def run(n_steps, batch, lookahead, first):
+        slots = lookahead + 1
+        c0 = be.counters()
+        t0 = time.perf_counter()
+        queued = 0
+        for s in range(n_steps):
+            while queued < n_steps and queued <= s + lookahead:
+                be.render(first + queued * batch, batch)
+                be.snapshot(queued % slots)
+                queued += 1
+            be.read_snapshot(s % slots, out=out)
+            callback()
+        dt = time.perf_counter() - t0
+        c1 = be.counters()
+        return (c1["segments"] - c0["segments"]) / dt / 1e6
+
+    run(4, 1, 2, 0)  # warm-up: staging, snapshot slots
+    n = 24
+    res = {"images": n,
+           "per_image_blocking_Msamples/s": run(n, 1, 0, 4),
+           "per_image_pipelined_Msamples/s": run(n, 1, 2, 4 + n),
+           "batch16_pipelined_Msamples/s": run(4, 16, 2, 4 + 2 * n),
+           "callbacks": calls[0],
+           "readback_bytes_per_image": W * H * 20,
+           "note": "includes the 20 B/pixel readback and the callback after every step; 'value' above is 16 iterations per launch "
+                   "with one readback at the end"}
+    res["per_image_vs_batched"] = res["per_image_pipelined_Msamples/s"] / batched_value
+    be.release()
+    return res
+
+
+def cpu_baseline(scene, W, H, D, rows, n_iter):
     """The CPU oracle (scalar C port of the reference kernel, test infrastructure) timed on the host cores
-    on a bounded sample of the SAME workload: iteration 0 of the first `rows` image rows, all host threads."""
+    on a bounded sample of the SAME workload: iterations 0..n-1 of the first `rows` image rows, all host threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
     cores = host_cores()
-    n_iter = 1
-    if rows <= 0:
-        # ~0.04 Mpaths/s/thread on this scene: aim at 10-30 s of CPU work, whole images first
-        target_paths = 15 * 0.04e6 * cores
-        n_iter = max(1, int(target_paths // (W * H)))
-        rows = H if n_iter >= 1 and target_paths >= W * H else max(cores, int(target_paths // W))
+    if rows <= 0 or n_iter <= 0:
+        # a short probe gives this scene's rate; then aim at ~15 s of CPU work, whole images first
+        probe_rows = max(cores, min(H, 4 * cores))
+        t0 = time.perf_counter()
+        _, _, _, tot = oracle_rows(O, scene, W, H, D, probe_rows, cores, 1)
+        rate = tot["paths"] / max(time.perf_counter() - t0, 1e-6)
+        target_paths = 15.0 * rate
+        if n_iter <= 0:
+            n_iter = max(1, min(64, int(target_paths // (W * H))))
+        if rows <= 0:
+            rows = H if target_paths >= W * H else max(cores, int(target_paths // W))
     t0 = time.perf_counter()
     _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores, n_iter)
     dt = time.perf_counter() - t0
@@ -249,7 +378,7 @@ def host_cores():
 
 
 def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1):
-    """Render iteration 0 for the first `rows` rows by running the oracle on a W x rows 'image' whose
+    """Render iterations 0..n_iter-1 for the first `rows` rows by running the oracle on a W x rows 'image' whose
     camera rays equal those of rows 0..rows-1 of the full image: seed and jitter depend on (x, y, W, H),
     so the full-size H is kept and only the row loop is cut short."""
     import ctypes as C
@@ -258,7 +387,6 @@ def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1):
     osc = O.OracleScene(scene, W, H, D)
     color = np.zeros((H, W, 4), np.float32)
     count = np.zeros((H, W), np.float32)
-    imgv = np.zeros((1,), np.float32)
     dep = np.zeros(D + 1, np.uint32)
     bbx = np.zeros(5000, np.uint32)
     tri = np.zeros(5000, np.uint32)

@@ -22,6 +22,7 @@
 #ifndef PTMI_H
 #define PTMI_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "ptmi_scene.h"
 
@@ -141,9 +142,15 @@ int ptmi_synchronize(ptmi_ctx* ctx);
 /* Replaces the two blocking clEnqueueReadBuffer of every image (OpenCL.cpp:97-98):
  * image_color = float[4*W*H] sum of radiance, image_ray_nb = float[W*H] sample
  * count.  Either pointer may be NULL.  Waits for everything queued so far.  The bytes cross the bus into pinned
- * memory: a host buffer handed in a second time is page-locked in place (and stays so until ptmi_release), a
- * one-off buffer goes through a pinned staging buffer of the context. */
+ * memory: straight into the destination if the caller has page-locked it (ptmi_pin_host_buffer), through a
+ * pinned staging buffer of the context and a host copy otherwise. */
 int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb);
+
+/* Page-lock a host buffer the caller will hand to ptmi_read_image / ptmi_read_snapshot again and again (the viewer's
+ * imageColor / imageRayNb, which the reference reads into after every image, OpenCL.cpp:97-98): readbacks then DMA
+ * into it without an intermediate copy.  The buffer must stay allocated until ptmi_unpin_host_buffer or ptmi_release. */
+int ptmi_pin_host_buffer(ptmi_ctx* ctx, void* buffer, size_t bytes);
+int ptmi_unpin_host_buffer(ptmi_ctx* ctx, void* buffer);
 
 /* The same readback split in two so that the launches of the NEXT images run while image k crosses the bus
  * (the reference blocks on every image: launch, clFinish, read, callback - OpenCL.cpp:85-103):

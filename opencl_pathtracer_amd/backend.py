@@ -82,7 +82,7 @@ FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront ker
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_write_image", "ptmi_snapshot", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
@@ -109,6 +109,8 @@ def load_library():
     lib.ptmi_read_image.argtypes = [vp, vp, vp]
     lib.ptmi_read_display.argtypes = [vp, vp, u32]
     lib.ptmi_snapshot.argtypes = [vp, u32]
+    lib.ptmi_pin_host_buffer.argtypes = [vp, vp, C.c_size_t]
+    lib.ptmi_unpin_host_buffer.argtypes = [vp, vp]
     lib.ptmi_read_snapshot.argtypes = [vp, u32, vp, vp]
     lib.ptmi_write_variance.argtypes = [vp, vp]
     lib.ptmi_write_image.argtypes = [vp, vp, vp]
@@ -236,21 +238,27 @@ class Backend:
     def clear(self):
         self._check(self._lib.ptmi_clear(self._ctx))
 
-    def read_image(self):
+    def read_image(self, out=None):
         """(imageColor float32[H,W,4], imageRayNb float32[H,W]) -- the per-image readback, OpenCL.cpp:97-98."""
         h, w = self.cfg.image_height, self.cfg.image_width
-        color = np.empty((h, w, 4), np.float32)
-        count = np.empty((h, w), np.float32)
+        color, count = out if out is not None else (np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32))
         self._check(self._lib.ptmi_read_image(self._ctx, _ptr(color), _ptr(count)))
         return color, count
+
+    def pin_host_buffer(self, array):
+        """Page-lock a numpy array that read_image / read_snapshot will fill repeatedly (keep it alive until unpin / release)."""
+        self._check(self._lib.ptmi_pin_host_buffer(self._ctx, _ptr(array), array.nbytes))
+
+    def unpin_host_buffer(self, array):
+        self._check(self._lib.ptmi_unpin_host_buffer(self._ctx, _ptr(array)))
 
     def snapshot(self, slot=0):
         """Queue a device-side copy of the accumulators behind the launches issued so far (ptmi_snapshot)."""
         self._check(self._lib.ptmi_snapshot(self._ctx, slot))
 
     def read_snapshot(self, slot=0, out=None):
-        """Wait for snapshot ``slot`` only and return it; ``out`` = (color, count) arrays to fill (reused buffers are
-        page-locked by the library from their second use on)."""
+        """Wait for snapshot ``slot`` only and return it; ``out`` = (color, count) arrays to fill (DMA'd into directly
+        if they were page-locked with pin_host_buffer)."""
         h, w = self.cfg.image_height, self.cfg.image_width
         color, count = out if out is not None else (np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32))
         self._check(self._lib.ptmi_read_snapshot(self._ctx, slot, _ptr(color), _ptr(count)))

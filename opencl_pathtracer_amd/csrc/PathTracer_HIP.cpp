@@ -32,8 +32,8 @@
 // The render loop keeps the reference's contract - after image k the host buffers hold the sum of images 0..k and the
 // callback runs - but does not idle the GPU while image k crosses the bus and the viewer paints it: the launches of the
 // next PTMI_LOOKAHEAD steps are already queued, and what is read back is a device-side snapshot taken right behind
-// image k's launch (ptmi_snapshot / ptmi_read_snapshot), DMA'd straight into the caller's buffers (page-locked from their
-// second use on).
+// image k's launch (ptmi_snapshot / ptmi_read_snapshot), DMA'd straight into the caller's buffers (page-locked for the
+// duration of OpenCL_RunKernel).
 //
 // Environment knobs (all optional):
 //   PTMI_DEVICES = "all" (default) or a comma-separated list of HIP ordinals;  PTMI_DEVICE = one ordinal (wins)
@@ -166,6 +166,10 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
     unsigned lookahead = env_uint("PTMI_LOOKAHEAD", g_devices > 2 ? g_devices : 2);
     if (lookahead > PTMI_MAX_SNAPSHOT_SLOTS - 2) lookahead = PTMI_MAX_SNAPSHOT_SLOTS - 2;  // one slot is the library's own
     const unsigned slots = lookahead + 1;
+    // the viewer's two buffers are read into after every image (OpenCL.cpp:97-98): page-locked once, so that each readback
+    // is one DMA (best effort: a buffer that cannot be locked goes through the library's staging buffer)
+    (void)ptmi_pin_host_buffer(g_ctx, globalVars.imageColor, sizeof(RGBAColor) * (size_t)globalVars.imageWidth * globalVars.imageHeight);
+    (void)ptmi_pin_host_buffer(g_ctx, globalVars.imageRayNb, sizeof(float) * (size_t)globalVars.imageWidth * globalVars.imageHeight);
     const uint steps = (numImagesToRender + batch - 1) / batch;
     // step s = images [s * batch, min((s + 1) * batch, numImagesToRender)): launch(es) + a snapshot behind them
     auto enqueue = [&](uint s) {

@@ -71,6 +71,15 @@ constexpr int kQueues = PTMI_WF_QUEUES;  // job queues (image stripes), one per 
 #endif
 constexpr int kQueueStride = PTMI_WF_QUEUE_STRIDE;  // dwords between two queue counters (64 = one 256-byte block each)
 constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
+#ifndef PTMI_WF_HIT_WORDS
+// LDS words of the closest-hit record per lane.  8: hit point (4), s, t, triangle | front, found.  4: the ray parameter
+// instead of the point - path logic rebuilds the point from the ray it still holds with the very operations of the
+// triangle test, bit for bit - s, t, and one word triangle | front | found.  LDS per workgroup = (tree depth + 1 + words)
+// KB: with 4 words trees up to depth 27 keep five workgroups per CU (8 words: up to depth 22; the 4M-triangle scene is 24).
+#define PTMI_WF_HIT_WORDS 8
+#endif
+constexpr int kHitWords = PTMI_WF_HIT_WORDS;
+static_assert(kHitWords == 4 || kHitWords == 8, "closest-hit record: 4 or 8 words");
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
 // rest of DScene (sky: only when a path escapes; histogram / RANDOM-sampler / SUPER_SAMPLING buffers; counters)
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // hit record, its address minus one level cannot wrap below zero).  Pushes write the slot above the top for
     // every lane and move the top only for pushing lanes; an inner node at depth k has at most k pending entries
     // above it, so that slot is always inside the `stack_levels` = tree depth levels.
-    uint32_t* const stack_floor = &stack_mem[8 * kWfBlock + tid];
+    uint32_t* const stack_floor = &stack_mem[kHitWords * kWfBlock + tid];
     *stack_floor = REF_NONE;
     // the rare fields: pointer re-derived through an opaque asm so the loads stay where they are used
     auto cold_scene = [&]() -> const DScene& {
@@ -152,6 +161,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // The closest-hit record (point, s, t, triangle, side) changes only when a closer hit is accepted and is read
     // only by path logic: it lives in LDS in front of the stack, [field][lane], not in registers of the hot loop.
     uint32_t* const hit_mem = &stack_mem[tid];
+    // the record's triangle word = triangle record index (< 2^27) | kHitFront when the ray met the front side (N . dir < 0)
+    // (| kHitFound in the 4-word record, whose last word it is; the 8-word record keeps "found" in a word of its own)
+    constexpr uint32_t kHitFront = 0x80000000u, kHitFound = 0x40000000u;
+    constexpr int kWordS = kHitWords == 8 ? 4 : 1, kWordT = kHitWords == 8 ? 5 : 2, kWordTri = kHitWords == 8 ? 6 : 3;
     const uint32_t tiles_x = (sc.width + 7u) >> 3;
     const bool owns_pixel = sc.sampler != PTMI_SAMPLER_RANDOM;
     const uint32_t n_tiles = (n_jobs / n_iterations) >> 6;
@@ -161,12 +174,13 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // Whether a lane has a path in flight, or is done for good, is kept IN `cur` (REF_IDLE / REF_DEAD) so that the
     // wave's three step masks come from three integer compares; the two bools below only live inside a path-logic trip.
     bool alive = true, need_path = true;
-    // iteration ids of this launch: first_iteration + k * iteration_stride, k = it_local < n_iterations (the stride is the
-    // number of devices that share a render: each takes the ids of its own residue class, ptmi_api.cpp)
-    uint32_t gx = 0, gy = 0, it_local = 0;
+    // The path's job as ONE word: its slot in the staging arrays = it_local * W * H + y * W + x.  Iteration ids of this
+    // launch: first_iteration + it_local * iteration_stride, it_local < n_iterations (the stride is the number of devices
+    // that share a render: each takes the ids of its own residue class, ptmi_api.cpp).  Pixel and iteration are only needed
+    // when the path starts; everything a lane keeps across traversal trips costs a register of the 96 (5 waves per SIMD).
+    uint32_t slot = 0;
     // path
     int seed = 1;
-    float sample_x = 0, sample_y = 0;
     V4 transfer = v4(1, 1, 1, 1), radiance = v4(0, 0, 0, 0);
     uint32_t reflection = 0, p_bbx = 0, p_tri = 0;
     bool in_water = false;
@@ -179,27 +193,39 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     bool wave_exact = true;    // ... and so does some ray of this wave (wave-uniform, refreshed after every path-logic pass)
     uint32_t cur = REF_IDLE, tri_i = 0, tri_end = 0;
     uint32_t* sp = stack_floor;  // the top entry (the sentinel when the stack is empty)
+    // the point of the closest hit, as path logic needs it when a query has finished
     auto load_hit_point = [&]() {
-        return v4(__uint_as_float(hit_mem[0 * kWfBlock]), __uint_as_float(hit_mem[1 * kWfBlock]),
-                  __uint_as_float(hit_mem[2 * kWfBlock]), __uint_as_float(hit_mem[3 * kWfBlock]));
+        if (kHitWords == 8)
+            return v4(__uint_as_float(hit_mem[0 * kWfBlock]), __uint_as_float(hit_mem[1 * kWfBlock]),
+                      __uint_as_float(hit_mem[2 * kWfBlock]), __uint_as_float(hit_mem[3 * kWfBlock]));
+        // 4-word record.  After a shadow query the lane's ray still starts at the hit point (:932-936 shoot from it without
+        // an offset); after a closest-hit query the ray is the one that found the hit, and the point is
+        // origin + direction * parameter evaluated as Triangle_Intersects does (FullKernel.cl:536).
+        if (shadow) return r.o;
+        return r.o + (r.d * __uint_as_float(hit_mem[0 * kWfBlock]));
     };
-    // saved across the shadow rays of one surface hit
-    Surface sf;
-    sf.Ng = sf.Ns = sf.color = v4(0, 0, 0, 0);
-    sf.mat.type = 0; sf.mat.opacity = 0; sf.mat.texture_id = 0; sf.mat.is_simple_color = 1;
-    sf.mat.color[0] = sf.mat.color[1] = sf.mat.color[2] = sf.mat.color[3] = 0;
+    auto query_found = [&]() {
+        return kHitWords == 8 ? (hit_mem[7 * kWfBlock] & 2u) != 0 : (hit_mem[kWordTri * kWfBlock] & kHitFound) != 0;
+    };
+    // saved across the shadow rays of one surface hit: the direction the surface was reached along and the light gathered
+    // so far.  The surface itself (normals, colour, material) is NOT kept: it is a pure function of the hit record in LDS
+    // and cam_d and is rebuilt where it is used (once per hit with one light), which frees ~15 registers of every trip.
     V4 cam_d = v4(0, 0, 0, 0), direct = v4(0, 0, 0, 0);
     uint32_t light_idx = 0;
-    // totals
-    unsigned long long n_bbx = 0, n_tri = 0;
-    uint32_t n_seg = 0, n_shadow = 0, n_hits = 0, n_paths = 0;
     // wave-uniform scheduler statistics (scalar registers): trips and active lanes per step kind
     uint32_t trips_i = 0, trips_t = 0, trips_p = 0;
     unsigned long long lanes_i = 0, lanes_t = 0, lanes_p = 0;
 
-    // statistics + accumulation of a finished path (FullKernel.cl:1319-1345)
-    auto finish_path = [&]() {
-        n_bbx += p_bbx; n_tri += p_tri; n_hits += reflection; n_paths++;
+    // statistics + accumulation of a finished path (FullKernel.cl:1319-1345).  `missed`: the path ended on a sky miss,
+    // i.e. it made one closest-hit query more than it has surface hits.
+    auto finish_path = [&](bool missed) {
+        // totals of the launch (ptmi_get_counters): added per finished path into the workgroup's LDS block - everything is
+        // a function of the three per-path counters, so no lane keeps running totals in registers
+        atomicAdd(&block_counters[C_PATHS], 1ull);
+        atomicAdd(&block_counters[C_HITS], (unsigned long long)reflection);
+        atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)(reflection + (missed ? 1u : 0u)));
+        atomicAdd(&block_counters[C_BBX], (unsigned long long)p_bbx);
+        atomicAdd(&block_counters[C_TRI], (unsigned long long)p_tri);
         if (sc.histograms && stage_stats == nullptr) {
             // RANDOM sampler / very deep paths: the three statistics atomics as the reference issues them (:1319-1331)
             const DScene& cs = cold_scene();
@@ -209,7 +235,6 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         }
         if (owns_pixel) {
             // JITTERED / UNIFORM: the sample lands on the work-item's own pixel (:1333-1336); stage it
-            const size_t slot = (size_t)it_local * ((size_t)sc.width * sc.height) + (size_t)gy * sc.width + gx;
             reinterpret_cast<float4*>(stage)[slot] = make_float4(radiance.x, radiance.y, radiance.z, radiance.w);
             // ... and its three histogram bins in one word; histogram_staged_kernel counts them afterwards in LDS.
             // (Three global atomics per path on a handful of hot bins cost 3 % on the 1M-triangle scene and 79 % on the
@@ -217,7 +242,15 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             if (stage_stats != nullptr) stage_stats[slot] = pack_path_statistics(reflection, p_bbx, p_tri);
             if (SS) cold_scene().stage_flag[slot] = 1.f;
         } else {
-            // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345)
+            // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345).  The sample
+            // position is drawn again from the path's seed (the first two draws, :1137-1141) instead of being kept.
+            const uint32_t n_pixels = sc.width * sc.height;
+            const uint32_t it_local = slot / n_pixels, pixel = slot - it_local * n_pixels;
+            const uint32_t gy = pixel / sc.width, gx = pixel - gy * sc.width;
+            const uint32_t it = first_iteration + it_local * iteration_stride;
+            int seed0 = lcg_seed(gx, gy, sc.width, sc.height, it);
+            float sample_x, sample_y;
+            draw_sample(sc, gx, gy, it, seed0, sample_x, sample_y);
             const uint32_t off = sample_pixel(sc, sample_x, sample_y);
             const DScene& cs = cold_scene();
             atomicAdd(&cs.image_color[4 * off + 0], radiance.x);
@@ -235,7 +268,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // the range is free.
     auto start_query = [&]() {
         cur = sc.root_ref; sp = stack_floor; tri_i = tri_end = 0;
-        hit_mem[7 * kWfBlock] = 0;  // "found" lives in the hit record: bit 1 of its last word (bit 0: front side)
+        // "found" of THIS query (a shadow query leaves the rest of the closest hit's record alone)
+        if (kHitWords == 8) hit_mem[7 * kWfBlock] = 0;
+        else if (shadow) atomicAnd(&hit_mem[kWordTri * kWfBlock], ~kHitFound);
+        else hit_mem[kWordTri * kWfBlock] = 0;
         exact_boxes = !(sc.boxes_ordered && ray_slabs_are_ordered(r));
         if (cur & REF_LEAF) {  // the whole scene is one leaf
             decode_leaf(sc, cur, tri_i, tri_end);
@@ -304,18 +340,24 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         // ---- one triangle test (Triangle_Intersects inside the leaf loop, FullKernel.cl:638-646)
                         p_tri++;
                         tri_test<PRE>(e0, e1, [&](float4& l0, float4& l1) { l0 = rec[kL0]; l1 = rec[kL1]; }, r, limit,
-                                      [&](const V4& q, float s, float t, bool front, float nsd) {
+                                      [&](const V4& q, float ray_t, float s, float t, bool front, float nsd) {
                             limit = nsd;
                             if (!shadow) {  // closest hit so far: the record path logic will shade from
-                                hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
-                                hit_mem[2 * kWfBlock] = __float_as_uint(q.z); hit_mem[3 * kWfBlock] = __float_as_uint(q.w);
-                                hit_mem[4 * kWfBlock] = __float_as_uint(s); hit_mem[5 * kWfBlock] = __float_as_uint(t);
-                                hit_mem[6 * kWfBlock] = tri_i; hit_mem[7 * kWfBlock] = front ? 3u : 2u;
+                                if (kHitWords == 8) {
+                                    hit_mem[0 * kWfBlock] = __float_as_uint(q.x); hit_mem[1 * kWfBlock] = __float_as_uint(q.y);
+                                    hit_mem[2 * kWfBlock] = __float_as_uint(q.z); hit_mem[3 * kWfBlock] = __float_as_uint(q.w);
+                                    hit_mem[6 * kWfBlock] = tri_i | (front ? kHitFront : 0u); hit_mem[7 * kWfBlock] = 2u;
+                                } else {
+                                    hit_mem[0 * kWfBlock] = __float_as_uint(ray_t);
+                                    hit_mem[kWordTri * kWfBlock] = tri_i | (front ? kHitFront : 0u) | kHitFound;
+                                }
+                                hit_mem[kWordS * kWfBlock] = __float_as_uint(s); hit_mem[kWordT * kWfBlock] = __float_as_uint(t);
                             } else {
                                 // any hit ends a shadow query (:724-727): empty the triangle range, drop the pending
                                 // node.  Written as in-place moves (tied asm operands) so that these two registers
                                 // are not merged back through the early exits with a select on every trip.
-                                hit_mem[7 * kWfBlock] = 2u;
+                                if (kHitWords == 8) hit_mem[7 * kWfBlock] = 2u;
+                                else atomicOr(&hit_mem[kWordTri * kWfBlock], kHitFound);
                                 asm volatile("v_mov_b32 %0, %1" : "+v"(tri_end) : "v"(tri_i));
                                 asm volatile("v_mov_b32 %0, -1" : "+v"(cur));
                             }
@@ -378,19 +420,16 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         if (want_post) {
             need_path = cur == REF_IDLE;
             alive = true;
-            bool end_path = false;
-            bool start_shadow = false, do_scatter = false;
+            bool end_path = false, missed = false;
+            bool start_shadow = false, do_scatter = false, lit = false;
             Hit hit;
             hit.point = v4(0, 0, 0, 0); hit.s = hit.t = 0; hit.tri = 0; hit.front = false;
             if (!need_path) {
                 hit.point = load_hit_point();
-                const bool found = (hit_mem[7 * kWfBlock] & 2u) != 0;
+                const bool found = query_found();
                 if (!shadow) {
                     // closest-hit query finished (FullKernel.cl:1252-1288)
                     if (found) {
-                        hit.s = __uint_as_float(hit_mem[4 * kWfBlock]); hit.t = __uint_as_float(hit_mem[5 * kWfBlock]);
-                        hit.tri = hit_mem[6 * kWfBlock]; hit.front = (hit_mem[7 * kWfBlock] & 1u) != 0;
-                        load_surface(sc, r, hit, sf);
                         cam_d = r.d;
                         direct = v4(0, 0, 0, 0);
                         light_idx = 0;
@@ -398,19 +437,44 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         else do_scatter = true;
                     } else {
                         radiance = radiance + (sky_color(cold_scene().sky, sc.texels, r.d) * transfer);
-                        end_path = true;
+                        end_path = missed = true;
                     }
                 } else {
                     // shadow query finished (Scene_ComputeDirectIllumination, :944-947)
-                    if (!found) {
+                    lit = !found;
+                    if (light_idx + 1u < sc.n_lights) start_shadow = true;
+                    else do_scatter = true;
+                }
+                if (lit || do_scatter) {
+                    // the surface of the closest hit (:1254-1274), rebuilt from the hit record and the arrival direction
+                    Surface sf;
+                    const uint32_t w6 = hit_mem[kWordTri * kWfBlock];
+                    hit.s = __uint_as_float(hit_mem[kWordS * kWfBlock]); hit.t = __uint_as_float(hit_mem[kWordT * kWfBlock]);
+                    hit.tri = w6 & REF_INDEX_MASK_LEAF; hit.front = (w6 & kHitFront) != 0;
+                    Ray arrival;
+                    arrival.o = hit.point; arrival.d = cam_d; arrival.ix = arrival.iy = arrival.iz = 0;
+                    load_surface(sc, arrival, hit, sf);
+                    if (lit) {
                         const ptmi_light light = sc.lights[light_idx];
                         const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
                         direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
                     }
-                    light_idx++;
-                    if (light_idx < sc.n_lights) start_shadow = true;
-                    else do_scatter = true;
+                    if (do_scatter) {
+                        r.d = cam_d;
+                        radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
+                        reflection++;
+                        shadow = false;
+                        const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // :1296-1304
+                        const float m = transfer.x < m_yz ? m_yz : transfer.x;
+                        if (m <= kMinContribution || reflection >= sc.max_depth) {
+                            end_path = true;
+                        } else {
+                            limit = INFINITY;
+                            start_query();
+                        }
+                    }
                 }
+                if (shadow) light_idx++;  // (still set: this pass finished a shadow query and did not scatter)
                 if (start_shadow) {
                     // :932-944: ray from the hit point (no offset) towards light `light_idx`
                     const ptmi_light light = sc.lights[light_idx];
@@ -421,24 +485,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
                     shadow = true;
                     start_query();
-                    n_shadow++;
                 }
-                if (do_scatter) {
-                    r.d = cam_d;
-                    radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
-                    reflection++;
-                    shadow = false;
-                    const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // :1296-1304
-                    const float m = transfer.x < m_yz ? m_yz : transfer.x;
-                    if (m <= kMinContribution || reflection >= sc.max_depth) {
-                        end_path = true;
-                    } else {
-                        limit = INFINITY;
-                        start_query();
-                        n_seg++;
-                    }
-                }
-                if (end_path) finish_path();
+                if (end_path) finish_path(missed);
             }
         }
 
@@ -447,6 +495,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         // workgroup's XCD group (blockIdx % 8: which blocks share an XCD and its L2, not which XCD - a speed matter
         // only) and moves on to the next one when its queue is exhausted, so neighbouring tiles run on one L2.
         bool got_job = false;
+        uint32_t gx = 0, gy = 0, it_local = 0;  // of the new job; live only until the path has started, below
         const bool want_job = want_post && need_path;
         const unsigned long long m_job = __ballot(want_job);
         if (m_job != 0ull) {
@@ -488,7 +537,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             // ---- start the next camera path of this pixel (FullKernel.cl:1208-1215) ------------
             if (got_job) {
                 const uint32_t it = first_iteration + it_local * iteration_stride;
+                slot = it_local * (sc.width * sc.height) + gy * sc.width + gx;
                 seed = lcg_seed(gx, gy, sc.width, sc.height, it);
+                float sample_x, sample_y;
                 draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
                 {
                     const DScene& cs = cold_scene();  // camera: only needed here, once per path
@@ -521,9 +572,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 if (sc.max_depth > 0) {
                     limit = INFINITY;
                     start_query();
-                    n_seg++;
                 } else {
-                    finish_path();  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
+                    finish_path(false);  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
                 }
             }
             if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
@@ -531,12 +581,6 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         wave_exact = __builtin_amdgcn_ballot_w64(exact_boxes) != 0ull;  // finished lanes keep a stale flag: conservative
     }
 
-    atomicAdd(&block_counters[C_PATHS], (unsigned long long)n_paths);
-    atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)n_seg);
-    atomicAdd(&block_counters[C_HITS], (unsigned long long)n_hits);
-    atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
-    atomicAdd(&block_counters[C_BBX], n_bbx);
-    atomicAdd(&block_counters[C_TRI], n_tri);
     if (STATS && (tid & 63u) == 0) {  // one lane per wave: the scheduler counters are wave-uniform
         atomicAdd(&block_counters[C_TRIPS_I], (unsigned long long)trips_i);
         atomicAdd(&block_counters[C_LANES_I], lanes_i);
@@ -545,6 +589,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         atomicAdd(&block_counters[C_TRIPS_P], (unsigned long long)trips_p);
         atomicAdd(&block_counters[C_LANES_P], lanes_p);
     }
+    __syncthreads();
+    // every surface hit sends one shadow ray to every light (Scene_ComputeDirectIllumination, :901-954)
+    if (tid == 0) block_counters[C_SHADOW] = block_counters[C_HITS] * sc.n_lights;
     __syncthreads();
     if (tid < C_COUNT) atomicAdd(&cold_scene().counters[tid], block_counters[tid]);
 }
@@ -645,7 +692,7 @@ static uint32_t clamp_levels(uint32_t stack_levels)
 static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
     stack_levels = clamp_levels(stack_levels);
-    return (size_t)(stack_levels + 9) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // closest-hit record + sentinel + stack
+    return (size_t)(stack_levels + 1 + ptmi_dev::kHitWords) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // closest-hit record + sentinel + stack
 }
 
 int wavefront_resident_blocks(int device, uint32_t stack_levels)

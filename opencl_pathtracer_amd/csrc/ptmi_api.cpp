@@ -80,8 +80,8 @@ struct ptmi_ctx {
     size_t display_bytes = 0;
     // host side of the readbacks
     float* h_staging = nullptr;  // pinned, 5*W*H floats
-    struct HostRange { void* p; size_t bytes; bool registered; };
-    std::vector<HostRange> seen_host;  // destination buffers seen so far; one seen twice is page-locked in place
+    struct HostRange { char* p; size_t bytes; };
+    std::vector<HostRange> pinned_host;  // caller buffers page-locked by ptmi_pin_host_buffer: readbacks DMA straight into them
 
     size_t npix() const { return (size_t)cfg.image_width * cfg.image_height; }
     uint32_t n_dev() const { return (uint32_t)dev.size(); }
@@ -528,17 +528,12 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     return PTMI_OK;
 }
 
-// Host buffer `p` as the destination of an asynchronous copy: page-locked in place from the second time it is seen
-// (the viewer's buffers, handed in after every image), through the context's pinned staging buffer before that.
+// Is [p, p + bytes) inside a buffer the caller has page-locked with ptmi_pin_host_buffer?  Then a readback is one DMA into
+// it; any other destination goes through the context's pinned staging buffer and a host memcpy.
 bool host_is_pinned(ptmi_ctx* ctx, void* p, size_t bytes)
 {
-    for (auto& r : ctx->seen_host) {
-        if (r.p != p || r.bytes != bytes) continue;
-        if (!r.registered && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) r.registered = true;
-        else if (!r.registered) (void)hipGetLastError();  // not registrable (already pinned elsewhere, odd mapping): staging
-        return r.registered;
-    }
-    if (ctx->seen_host.size() < 8) ctx->seen_host.push_back({p, bytes, false});
+    for (auto& r : ctx->pinned_host)
+        if ((char*)p >= r.p && (char*)p + bytes <= r.p + r.bytes) return true;
     return false;
 }
 
@@ -852,6 +847,39 @@ int ptmi_read_image(ptmi_ctx* ctx, float* image_color, float* image_ray_nb)
     return ptmi_read_snapshot(ctx, kInternalSlot, image_color, image_ray_nb);
 }
 
+int ptmi_pin_host_buffer(ptmi_ctx* ctx, void* buffer, size_t bytes)
+{
+    if (!ctx || !buffer || bytes == 0) return PTMI_ERR_INVALID_ARGUMENT;
+    if (host_is_pinned(ctx, buffer, bytes)) return PTMI_OK;
+    if (ctx->dev.empty()) return PTMI_ERR_STATE;
+    ON_DEVICE(ctx, ctx->dev[0]);
+    const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: readbacks into this buffer simply keep using the staging path
+        return fail(ctx, PTMI_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    }
+    ctx->pinned_host.push_back({(char*)buffer, bytes});
+    return PTMI_OK;
+}
+
+int ptmi_unpin_host_buffer(ptmi_ctx* ctx, void* buffer)
+{
+    if (!ctx || !buffer) return PTMI_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < ctx->pinned_host.size(); i++) {
+        if (ctx->pinned_host[i].p != (char*)buffer) continue;
+        for (DeviceState& d : ctx->dev) {  // no copy into it may be in flight
+            ON_DEVICE(ctx, d);
+            HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+            if (d.copy_stream) HIP_TRY(ctx, hipStreamSynchronize(d.copy_stream));
+        }
+        (void)hipHostUnregister(buffer);
+        (void)hipGetLastError();
+        ctx->pinned_host.erase(ctx->pinned_host.begin() + (long)i);
+        return PTMI_OK;
+    }
+    return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "ptmi_unpin_host_buffer: not a buffer ptmi_pin_host_buffer has page-locked");
+}
+
 int ptmi_write_image(ptmi_ctx* ctx, const float* image_color, const float* image_ray_nb)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
@@ -1044,8 +1072,8 @@ void ptmi_release(ptmi_ctx* ctx)
 {
     if (!ctx) return;
     free_scene_memory(ctx);
-    for (auto& r : ctx->seen_host)
-        if (r.registered) (void)hipHostUnregister(r.p);
+    for (auto& r : ctx->pinned_host) (void)hipHostUnregister(r.p);
+    (void)hipGetLastError();
     if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);
     for (DeviceState& d : ctx->dev) {
         (void)hipSetDevice(d.device);

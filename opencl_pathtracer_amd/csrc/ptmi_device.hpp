@@ -232,7 +232,7 @@ __device__ __forceinline__ bool tri_hit_record(const float4 a, const float4 b, c
 }
 
 // The same test shaped for the wavefront kernel's instruction budget (it is VALU-issue bound): two nesting levels
-// instead of five, and the accepted hit is consumed by `on_accept(q, s, t, front, nsd)` INSIDE the innermost
+// instead of five, and the accepted hit is consumed by `on_accept(q, ray parameter, s, t, front, nsd)` INSIDE the innermost
 // block, so no value has to be merged back through the early exits (each merge level cost a v_mov per live value).
 // The rejections are the reference's (FullKernel.cl:519-589) with unchanged operands; only their order differs -
 // the behind-the-ray test (:566) moves up next to the distance tests - which cannot change the outcome because the
@@ -248,7 +248,8 @@ __device__ __forceinline__ void tri_test(const float4 e0, const float4 e1, LateQ
     const V4 N = PRE ? v4(e0) : v4(e1);
     const float d = PRE ? e1.w : dot(v4(e1), v4(e0));
     const float nd = dot(N, r.d);
-    const V4 q = r.o + (r.d * ((d - dot(N, r.o)) / nd));
+    const float ray_t = (d - dot(N, r.o)) / nd;
+    const V4 q = r.o + (r.d * ray_t);
     const V4 full = q - r.o;
     const float nsd = dot(full, full);
     const float fd = dot(full, r.d);
@@ -271,7 +272,7 @@ __device__ __forceinline__ void tri_test(const float4 e0, const float4 e1, LateQ
         const float denom = PRE ? l0.w : 1 / (uv * uv - uu * vv);
         const float s = (uv * wv - vv * wu) * denom;
         const float t = (uv * wu - uu * wv) * denom;
-        if (!((s < 0) | (t < 0) | (s + t > 1))) on_accept(q, s, t, nd < 0, nsd);
+        if (!((s < 0) | (t < 0) | (s + t > 1))) on_accept(q, ray_t, s, t, nd < 0, nsd);
     }
 }
 

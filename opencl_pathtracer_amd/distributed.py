@@ -31,13 +31,25 @@ class FusedAccumulators:
         self.buffer = torch.zeros(5 * self.npix, dtype=torch.float32, device=device)
         self.color = self.buffer[: 4 * self.npix]
         self.count = self.buffer[4 * self.npix:]
+        self._backend = None
 
     def bind(self, backend):
-        """Make the integrator accumulate straight into this tensor (ptmi_bind_accumulators)."""
+        """Make the integrator accumulate straight into this tensor (ptmi_bind_accumulators).  The zero fill above ran
+        on torch's current stream and the integrator has a stream of its own: wait for the fill before binding."""
+        if self.buffer.is_cuda:
+            torch.cuda.current_stream(self.buffer.device).synchronize()
         backend.bind_accumulators(self.color.data_ptr(), self.count.data_ptr())
+        self._backend = backend
 
-    def reduce_to(self, dst=0, group=None):
-        """The one collective of a sharded render: sum over ranks onto `dst`."""
+    def reduce_to(self, dst=0, group=None, ordered=False):
+        """The one collective of a sharded render: sum over ranks onto `dst`.
+
+        Stream contract: the collective runs on torch's CURRENT stream, the launches on the backend's stream.  Unless the
+        caller states that they are the same stream (``ordered=True``, after ``backend.set_stream(current_stream)`` with a
+        non-default stream, as bench.py does) the host waits for the integrator here, so the reduce can never read
+        accumulators that are still being written."""
+        if self._backend is not None and not ordered:
+            self._backend.synchronize()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.reduce(self.buffer, dst=dst, op=dist.ReduceOp.SUM, group=group)
 
@@ -119,9 +131,13 @@ class ProgressiveDisplay:
         self.side = torch.cuda.Stream(accumulators.buffer.device) if self.on_gpu else None
         self.work = None
 
-    def submit(self):
-        """Snapshot now (ordered after the launches already queued on the current stream), reduce in the background."""
+    def submit(self, ordered=False):
+        """Snapshot now, reduce in the background.  The snapshot copy runs on torch's current stream: it is ordered after
+        the launches already queued only if that is the backend's stream too (``ordered=True``, see
+        FusedAccumulators.reduce_to); otherwise the host waits for the integrator first."""
         self.wait()
+        if self.acc._backend is not None and not ordered:
+            self.acc._backend.synchronize()
         self.snapshot.copy_(self.acc.buffer, non_blocking=True)
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
             return

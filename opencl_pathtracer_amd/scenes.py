@@ -457,12 +457,96 @@ def material_mix(width, height):
                  name="matmix")
 
 
+FEATURES = ("plain", "glass", "water", "varnish", "varnish_textured", "textured", "metal", "two_sided", "fallback_normals",
+            "spot", "directional", "cubemap")
+
+
+def feature_scene(feature, width, height):
+    """One kernel feature at a time on the same small stage (floor, back wall, one smooth sphere, one light, one
+    specialisation of the reference kernel: 1 light): the parity tests use these to tell WHICH branch of the integrator a
+    difference against the reference comes from.  ``plain`` is the control (diffuse colours, point light, black sky)."""
+    if feature not in FEATURES:
+        raise ValueError(f"unknown feature {feature!r}")
+    texels = []
+    textures = []
+
+    def add_tex(img, w, h):
+        off = sum(len(t) for t in texels)
+        texels.append(img)
+        textures.append((w, h, off))
+        return len(textures) - 1
+
+    if feature == "cubemap":
+        sky = np.zeros((), dtype=S.Sky)
+        sky["cosRotationAngle"] = f32(np.cos(0.7))
+        sky["sinRotationAngle"] = f32(np.sin(0.7))
+        sky["groundScale"] = 1
+        cols = [((40, 40, 60), (90, 90, 140)), ((200, 120, 60), (250, 220, 160)), ((60, 140, 200), (160, 220, 250)),
+                ((120, 200, 120), (220, 250, 220)), ((200, 200, 80), (250, 250, 200)), ((120, 160, 250), (230, 240, 255))]
+        for i, (c0, c1) in enumerate(cols):
+            off = sum(len(t) for t in texels)
+            texels.append(_gradient(16, 16, c0, c1))
+            sky["skyTextures"][i] = (16, 16, off)
+    else:
+        sky, t0 = no_sky((0, 0, 0, 0))
+        texels.append(t0)
+
+    FLOOR, WALL, BALL, BACK = 0, 1, 2, 3
+    mats = [material_create(color=(0.75, 0.75, 0.7, 0)), material_create(color=(0.3, 0.45, 0.8, 0)),
+            material_create(color=(0.8, 0.25, 0.2, 0)), material_create(color=(0.2, 0.7, 0.3, 0))]
+    if feature == "glass":
+        mats[BALL] = material_create(S.MAT_GLASS, color=(0.9, 0.95, 1.0, 0), opacity=0.1)
+    elif feature == "water":
+        mats[BALL] = material_create(S.MAT_WATER, color=(0.5, 0.7, 0.9, 0))
+    elif feature == "varnish":
+        mats[BALL] = material_create(S.MAT_VARNHISHED, color=(0.2, 0.6, 0.3, 0))
+    elif feature == "varnish_textured":
+        mats[BALL] = material_create(S.MAT_VARNHISHED, texture_id=add_tex(_gradient(24, 8, (150, 90, 40), (220, 170, 90)), 24, 8))
+    elif feature == "textured":
+        mats[FLOOR] = material_create(S.MAT_STANDART, texture_id=add_tex(_checker(32, 32, (230, 230, 230, 0), (40, 40, 160, 0)), 32, 32))
+        mats[BALL] = material_create(S.MAT_STANDART, texture_id=add_tex(_gradient(24, 8, (150, 90, 40), (220, 170, 90)), 24, 8))
+    elif feature == "metal":
+        mats[BALL] = material_create(S.MAT_METAL, color=(0.9, 0.9, 0.9, 0))
+
+    parts = []
+    g = 4
+    xs = np.linspace(-5, 5, g + 1)
+    for i in range(g):
+        for j in range(g):
+            a, b, c, d = (xs[i], xs[j], 0), (xs[i + 1], xs[j], 0), (xs[i + 1], xs[j + 1], 0), (xs[i], xs[j + 1], 0)
+            s1, s2, s3 = _quad(a, b, c, d)
+            uv = np.array([[(i, j), (i + 1, j), (i + 1, j + 1)], [(i, j), (i + 1, j + 1), (i, j + 1)]], f32) * f32(0.5)
+            parts.append(triangle_create(s1, s2, s3, uvp=uv, uvn=uv, mat_pos=FLOOR, mat_neg=FLOOR))
+    s1, s2, s3 = _quad((-5, 5, 0), (5, 5, 0), (5, 5, 4), (-5, 5, 4))
+    wall_normals = np.zeros((2, 3, 3), f32) if feature == "fallback_normals" else None  # zero -> N, which carries w = 1
+    parts.append(triangle_create(s1, s2, s3, normals=wall_normals, mat_pos=WALL, mat_neg=BACK if feature == "two_sided" else WALL))
+    parts.append(_sphere_tris((0.0, 1.0, 1.2), 1.2, 2, BALL, mat_neg=BACK if feature == "two_sided" else None))
+    if feature == "two_sided":  # a free-standing sheet seen from both sides
+        s1, s2, s3 = _quad((-4, -1, 0), (-2, 1, 0), (-2, 1, 2.5), (-4, -1, 2.5))
+        parts.append(triangle_create(s1, s2, s3, mat_pos=BALL, mat_neg=BACK))
+    tris = _concat_tris(parts)
+
+    if feature == "spot":
+        light = light_spot((-3.0, -4.0, 6.0), (0.45, 0.7, -1.0), cone_angle=0.8, penumbra_angle=0.3, color=(0.9, 0.9, 1, 1), intensity=12.0)
+    elif feature == "directional":
+        light = light_directional((-0.3, 0.4, -1.0), color=(1, 1, 0.9, 1), power=1.2)
+    else:
+        light = light_point((3.0, -4.0, 6.0), color=(1, 0.95, 0.9, 1), power=60.0)
+    lights = _records([light], S.Light)
+    span = 0.9
+    pos, d, r, u = camera((0.5, -10.0, 3.0), (0, 1, -0.2), (span, 0, 0), (0, 0.2 * span * height / width, span * height / width))
+    return Scene(tris, lights, _records(mats, S.Material), np.array(textures, dtype=S.Texture) if textures else np.zeros(0, S.Texture),
+                 np.concatenate(texels), sky, pos, d, r, u, name="feat_" + feature)
+
+
 def build(name, width, height):
     """Named scenes used by tests, fixtures and the bench."""
     if name == "cornell":
         return cornell_box(width, height)
     if name == "matmix":
         return material_mix(width, height)
+    if name.startswith("feat_"):
+        return feature_scene(name[5:], width, height)
     if name.startswith("tris"):
         spec = name[4:]
         n = int(spec[:-1]) * {"k": 1000, "m": 1000000}[spec[-1]] if spec[-1] in "km" else int(spec)

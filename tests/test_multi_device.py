@@ -122,7 +122,8 @@ def test_snapshot_ring_equals_blocking_loop(devices, scene_factory):
 
     be = Backend().setup_context(w, h, d, sc.lightsSize, devices=devices)
     be.initialize_memory(sc)
-    out = (np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32))  # reused: page-locked from the second read on
+    out = (np.empty((h, w, 4), np.float32), np.empty((h, w), np.float32))
+    be.pin_host_buffer(out[0])  # colour goes by DMA, the count through the staging buffer
     queued = 0
     for i in range(n_img):
         while queued < n_img and queued <= i + lookahead:
@@ -136,6 +137,11 @@ def test_snapshot_ring_equals_blocking_loop(devices, scene_factory):
         be.read_snapshot(slots + 1)  # never filled
     with pytest.raises(PtmiError):
         be.snapshot(99)
+    be.unpin_host_buffer(out[0])
+    with pytest.raises(PtmiError):
+        be.unpin_host_buffer(out[1])  # never pinned
+    c, n = be.read_image(out=out)  # staging path again
+    assert np.array_equal(c.view(np.uint32), expect[-1][0].view(np.uint32))
     be.release()
 
 

