@@ -750,27 +750,38 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         }
 #undef PTMI_LAUNCH_WF
         e = hipGetLastError();
-        if (e == hipSuccess && sc.sampler != PTMI_SAMPLER_RANDOM) {
-            const uint32_t n_pixels = sc.width * sc.height;
-            if (sc.super_sampling)
-                hipLaunchKernelGGL(ptmi_dev::accumulate_staged_ss_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
-                                   (hipStream_t)stream, sc.image_color, sc.image_ray_nb, sc.image_v, stage,
-                                   sc.stage_flag, n_pixels, first_iteration);
-            else
-                hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
-                                   (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
-            if (stage_stats != nullptr) {  // the launch's paths into the three histograms
-                const uint32_t n_slots = n_pixels * n_iterations;
-                uint32_t hb = (n_slots + 1023u) / 1024u;
-                if (hb > 512u) hb = 512u;
-                hipLaunchKernelGGL(ptmi_dev::histogram_staged_kernel, dim3(hb), dim3(1024), 0, (hipStream_t)stream, sc.hist_depths,
-                                   sc.hist_bbx, sc.hist_tri, stage_stats, sc.super_sampling ? sc.stage_flag : nullptr, n_slots);
-            }
-            e = hipGetLastError();
-        }
     }
     if (e != hipSuccess) {
         if (err) *err = std::string("render_wavefront_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    return PTMI_OK;
+}
+
+// What follows a wavefront launch of a sampler that owns its pixels: the staged radiances into the accumulators (per pixel,
+// in iteration order) and the staged statistics words into the three histograms.  May run on another stream than the
+// launch (the caller orders them with an event): these two small kernels are what keeps launches in iteration order.
+int launch_accumulate_staged(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,
+                             const uint32_t* stage_stats, void* stream, std::string* err)
+{
+    if (n_iterations == 0 || sc.sampler == PTMI_SAMPLER_RANDOM) return PTMI_OK;
+    const uint32_t n_pixels = sc.width * sc.height;
+    if (sc.super_sampling)
+        hipLaunchKernelGGL(ptmi_dev::accumulate_staged_ss_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+                           (hipStream_t)stream, sc.image_color, sc.image_ray_nb, sc.image_v, stage, sc.stage_flag, n_pixels, first_iteration);
+    else
+        hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+                           (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
+    if (stage_stats != nullptr) {  // the launch's paths into the three histograms
+        const uint32_t n_slots = n_pixels * n_iterations;
+        uint32_t hb = (n_slots + 1023u) / 1024u;
+        if (hb > 512u) hb = 512u;
+        hipLaunchKernelGGL(ptmi_dev::histogram_staged_kernel, dim3(hb), dim3(1024), 0, (hipStream_t)stream, sc.hist_depths,
+                           sc.hist_bbx, sc.hist_tri, stage_stats, sc.super_sampling ? sc.stage_flag : nullptr, n_slots);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("accumulate_staged_kernel launch: ") + hipGetErrorString(e);
         return PTMI_ERR_HIP;
     }
     return PTMI_OK;

@@ -48,8 +48,19 @@ struct DeviceState {
     uint32_t* d_hist = nullptr;  // depths | bbx | tri
     unsigned long long* d_counters = nullptr;
     uint32_t* d_job_counter = nullptr;
-    float* d_stage = nullptr;  // staged radiances [iteration][pixel] float4 (+ one statistics word) of the launch in flight
+    // Staged radiances [iteration][pixel] float4 (+ one statistics word per path) of the launches in flight.  TWO sets, each
+    // with a launch stream and job-queue counters of its own: consecutive launches alternate between them, so that the
+    // ramp-up of launch k+1 fills the CUs the tail of launch k leaves idle (a persistent launch ends ragged: its last paths
+    // finish one by one).  What keeps the results those of sequential launches: the staged values reach the accumulators
+    // on the ONE main stream, launch after launch (launch_accumulate_staged), and set k % 2 is reused by launch k + 2
+    // only after launch k's have been added (stage_free).
+    float* d_stage[2] = {nullptr, nullptr};
     size_t stage_iterations = 0;
+    hipStream_t launch_stream[2] = {nullptr, nullptr};
+    hipEvent_t rendered[2] = {nullptr, nullptr};    // recorded on launch_stream[i] behind the kernel
+    hipEvent_t stage_free[2] = {nullptr, nullptr};  // recorded on the main stream behind the accumulation
+    bool stage_busy[2] = {false, false};
+    uint32_t launches_issued = 0;
     int resident_blocks = 0;
     DScene ds{};
     DScene* d_scene = nullptr;  // device copy of ds (what the wavefront kernel's path logic reads)
@@ -119,8 +130,12 @@ void free_scene_memory(ptmi_ctx* ctx)
         d.d_counters = nullptr;
         d.d_job_counter = nullptr;
         d.d_scene = nullptr;
-        if (d.d_stage) (void)hipFree(d.d_stage);
-        d.d_stage = nullptr;
+        for (int i = 0; i < 2; i++) {
+            if (d.launch_stream[i]) (void)hipStreamSynchronize(d.launch_stream[i]);
+            if (d.d_stage[i]) (void)hipFree(d.d_stage[i]);
+            d.d_stage[i] = nullptr;
+            d.stage_busy[i] = false;
+        }
         d.stage_iterations = 0;
         for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++) {
             if (d.d_snapshot[k]) (void)hipFree(d.d_snapshot[k]);
@@ -410,8 +425,8 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     if (int rc = device_alloc(ctx, d, npix * 16, &dc)) return rc;
     if (int rc = device_alloc(ctx, d, npix * 4, &dn)) return rc;
     if (int rc = device_alloc(ctx, d, hist_words * 4, &dh)) return rc;
-    // counters, then the job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart)
-    if (int rc = device_alloc(ctx, d, C_COUNT * 8 + 256 + 8 * 1024 * 4, &dk)) return rc;
+    // counters, then two sets of job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart)
+    if (int rc = device_alloc(ctx, d, C_COUNT * 8 + 256 + 2 * 8 * 1024 * 4, &dk)) return rc;
     if (int rc = device_alloc(ctx, d, sizeof(DScene), &dsc)) return rc;
     d.d_scene = (DScene*)dsc;
     d.d_color = (float*)dc; d.d_count = (float*)dn; d.d_hist = (uint32_t*)dh;
@@ -468,19 +483,35 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     if (d.pending_events.size() >= 512)
         if (int rc = fold_events(ctx, d)) return rc;
     const bool megakernel = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0;
+    const bool staged = !megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM;
+    // alternate launch streams: only where the launch itself neither reads nor writes the accumulators (staged results, no
+    // adaptive sampling), on the context's own stream, and unless switched off (PTMI_SERIAL_LAUNCHES: developer A/B switch)
+    static const bool serial_env = std::getenv("PTMI_SERIAL_LAUNCHES") != nullptr;
+    const bool overlap = staged && !ctx->cfg.super_sampling && d.stream == d.own_stream && !serial_env;
     const size_t npix = ctx->npix();
-    if (!megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM) {
-        // staging array for the launch: grows on demand, capped by iterations_per_launch
+    if (staged) {
+        // staging arrays for the launches: grow on demand, capped by iterations_per_launch
         const size_t want = n < ctx->iterations_per_launch ? n : ctx->iterations_per_launch;
         if (want > d.stage_iterations) {
             HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-            if (d.d_stage) (void)hipFree(d.d_stage);
-            d.d_stage = nullptr;
+            for (int i = 0; i < 2; i++) {
+                if (d.launch_stream[i]) HIP_TRY(ctx, hipStreamSynchronize(d.launch_stream[i]));
+                if (d.d_stage[i]) (void)hipFree(d.d_stage[i]);
+                d.d_stage[i] = nullptr;
+                d.stage_busy[i] = false;
+            }
             d.stage_iterations = 0;
-            void* p = nullptr;
-            HIP_TRY(ctx, hipMalloc(&p, want * npix * 20));  // float4 radiance + one statistics word per path
-            d.d_stage = (float*)p;
+            for (int i = 0; i < 2; i++) {
+                void* p = nullptr;
+                HIP_TRY(ctx, hipMalloc(&p, want * npix * 20));  // float4 radiance + one statistics word per path
+                d.d_stage[i] = (float*)p;
+            }
             d.stage_iterations = want;
+        }
+        for (int i = 0; i < 2 && overlap; i++) {
+            if (!d.launch_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&d.launch_stream[i], hipStreamNonBlocking));
+            if (!d.rendered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.rendered[i], hipEventDisableTiming));
+            if (!d.stage_free[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.stage_free[i], hipEventDisableTiming));
         }
     }
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -496,33 +527,53 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     }
     std::string err;
     int rc = PTMI_OK;
+    // Both events on the MAIN stream: [previous launch accumulated, this one accumulated].  With alternating launch streams
+    // the intervals still tile the time line (no double counting of the overlap).
     hipError_t e = hipEventRecord(ev.first, d.stream);
     if (e == hipSuccess) {
         if (megakernel) {
             rc = launch_render(d.ds, first, n, stride, d.stream, &err);
         } else {
-            // histograms: staged per path and counted after the launch, unless there is no staging (RANDOM sampler),
-            // no histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
-            uint32_t* stage_stats = nullptr;
-            if (d.d_stage && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)
-                stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d.d_stage) + d.stage_iterations * npix * 16);
-            // one launch per chunk of iterations; chunks run back to back on the stream, in order
-            for (uint32_t done = 0; done < n && rc == PTMI_OK;) {
+            // one launch per chunk of iterations
+            for (uint32_t done = 0; done < n && rc == PTMI_OK && e == hipSuccess;) {
                 // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
                 const uint32_t cap = ctx->cfg.super_sampling ? 1u : ctx->iterations_per_launch;
                 const uint32_t m = n - done < cap ? n - done : cap;
-                rc = launch_render_wavefront(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter, d.resident_blocks,
-                                             ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, d.d_stage,
-                                             stage_stats, d.stream, &err);
+                const int set = overlap ? (int)(d.launches_issued & 1u) : 0;
+                hipStream_t ls = overlap ? d.launch_stream[set] : d.stream;
+                float* stage = staged ? d.d_stage[set] : nullptr;
+                // histograms: staged per path and counted after the launch, unless there is no staging (RANDOM sampler),
+                // no histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
+                uint32_t* stage_stats = nullptr;
+                if (stage && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)
+                    stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + d.stage_iterations * npix * 16);
+                if (overlap && d.stage_busy[set]) e = hipStreamWaitEvent(ls, d.stage_free[set], 0);
+                if (e != hipSuccess) break;
+                rc = launch_render_wavefront(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter + set * 8 * 1024,
+                                             d.resident_blocks, ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, stage,
+                                             stage_stats, ls, &err);
+                if (rc != PTMI_OK) break;
+                if (overlap) {
+                    e = hipEventRecord(d.rendered[set], ls);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(d.stream, d.rendered[set], 0);
+                    if (e != hipSuccess) break;
+                }
+                rc = launch_accumulate_staged(d.ds, first + done * stride, m, stage, stage_stats, d.stream, &err);
+                if (rc != PTMI_OK) break;
+                if (overlap) {
+                    e = hipEventRecord(d.stage_free[set], d.stream);
+                    d.stage_busy[set] = true;
+                }
+                d.launches_issued++;
                 done += m;
             }
         }
-        e = hipEventRecord(ev.second, d.stream);
+        if (e == hipSuccess) e = hipEventRecord(ev.second, d.stream);
     }
     if (e != hipSuccess || rc != PTMI_OK) {
         d.free_events.push_back(ev);  // never timed: back to the pool
         if (rc != PTMI_OK) return fail(ctx, rc, err);
-        return fail(ctx, PTMI_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+        return fail(ctx, PTMI_ERR_HIP, std::string("launch sequencing: ") + hipGetErrorString(e));
     }
     d.pending_events.push_back(ev);
     return PTMI_OK;
@@ -773,11 +824,15 @@ int ptmi_clear(ptmi_ctx* ctx)
     const size_t hist_words = (size_t)ctx->cfg.ray_max_depth + 1 + 2 * PTMI_MAX_INTERSECTION_NUMBER;
     for (DeviceState& d : ctx->dev) {
         ON_DEVICE(ctx, d);
+        // (every launch is followed by its accumulation on the main stream, so main-stream order covers the launch streams)
         HIP_TRY(ctx, hipMemsetAsync(d.ds.image_color, 0, npix * 16, d.stream));
         HIP_TRY(ctx, hipMemsetAsync(d.ds.image_ray_nb, 0, npix * 4, d.stream));
         HIP_TRY(ctx, hipMemsetAsync(d.d_hist, 0, hist_words * 4, d.stream));
         HIP_TRY(ctx, hipMemsetAsync(d.d_counters, 0, C_COUNT * 8, d.stream));
         if (d.ds.image_v) HIP_TRY(ctx, hipMemsetAsync(d.ds.image_v, 0, npix * 16, d.stream));
+        // a launch queued AFTER this call runs on a launch stream of its own and adds to the counters when it ends: it must
+        // not overtake the memsets above
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
     }
     return PTMI_OK;
 }
@@ -1082,6 +1137,11 @@ void ptmi_release(ptmi_ctx* ctx)
         for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++)
             if (d.snapshot_ready[k]) (void)hipEventDestroy(d.snapshot_ready[k]);
         if (d.peer_copied) (void)hipEventDestroy(d.peer_copied);
+        for (int i = 0; i < 2; i++) {
+            if (d.rendered[i]) (void)hipEventDestroy(d.rendered[i]);
+            if (d.stage_free[i]) (void)hipEventDestroy(d.stage_free[i]);
+            if (d.launch_stream[i]) (void)hipStreamDestroy(d.launch_stream[i]);
+        }
         if (d.own_stream) (void)hipStreamDestroy(d.own_stream);
         if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
     }

@@ -34,15 +34,42 @@ __device__ __forceinline__ V4 operator/(V4 a, float s) { return V4{a.x / s, a.y 
 __device__ __forceinline__ V4 operator-(V4 a) { return V4{-a.x, -a.y, -a.z, -a.w}; }
 
 // The OpenCL geometric builtins, fixed to the definitions of the OpenCL library the reference meets on
-// this hardware (ROCm device libs, opencl.bc), as far as they are exactly reproducible off the GPU:
-// dot and cross are its FMA chains verbatim; normalize scales by 1/sqrt(dot) where the library scales by
-// v_rsq_f32(dot) (a 1-ulp hardware approximation no CPU checker could follow).  DESIGN.md "Numerics".
+// this hardware (ROCm device libs, opencl.bc): dot and cross are its FMA chains verbatim, normalize below.
+// DESIGN.md "Numerics".
 __device__ __forceinline__ float dot(V4 a, V4 b)
 {
     return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
 }
 __device__ __forceinline__ float length(V4 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ V4 normalize(V4 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+// normalize(float4) of the ROCm OpenCL library (opencl.bc, _Z9normalizeDv4_f): the vector times rsqrt(dot), where rsqrt is
+// __ocml_rsqrt_f32 = the hardware's v_rsq_f32 (one ulp off the correctly rounded value for 11 % of the inputs) behind range
+// scaling for tiny / infinite squared lengths; the zero vector is returned as it is.  Written out in full so that the
+// integrator and the reference kernel compiled for this GPU agree to the last bit; the CPU checker reproduces v_rsq_f32
+// from a table measured on the hardware (oracle/pt_oracle.c).
+__device__ __forceinline__ float cl_rsqrt(float x)
+{
+    const bool tiny = x < 0x1p-126f;
+    const float r = __builtin_amdgcn_rsqf(tiny ? x * 0x1p+24f : x);
+    return tiny ? r * 4096.0f : r;
+}
+__device__ __forceinline__ V4 normalize(V4 a)
+{
+    if ((a.x == 0) & (a.y == 0) & (a.z == 0) & (a.w == 0)) return a;
+    float d = dot(a, a);
+    if (d < 0x1p-126f) {
+        a = a * 0x1p+86f;
+        d = dot(a, a);
+    } else if (d == INFINITY) {
+        a = a * 0x1p-66f;
+        d = dot(a, a);
+        if (d == INFINITY) {
+            a = V4{__builtin_copysignf(__builtin_isinf(a.x) ? 1.0f : 0.0f, a.x), __builtin_copysignf(__builtin_isinf(a.y) ? 1.0f : 0.0f, a.y),
+                   __builtin_copysignf(__builtin_isinf(a.z) ? 1.0f : 0.0f, a.z), __builtin_copysignf(__builtin_isinf(a.w) ? 1.0f : 0.0f, a.w)};
+            d = dot(a, a);
+        }
+    }
+    return a * cl_rsqrt(d);
+}
 __device__ __forceinline__ V4 cross(V4 a, V4 b)
 {
     return V4{__builtin_fmaf(a.y, b.z, b.y * -a.z), __builtin_fmaf(a.z, b.x, b.z * -a.x),
@@ -76,13 +103,15 @@ __device__ __forceinline__ float lcg_random(int& seed)
     return (float)seed / 2147483648.0f;
 }
 
-// InitializeRandomSeed, header.cl:255-264 (all arithmetic is modulo 2^32)
+// InitializeRandomSeed, header.cl:255-264 (all arithmetic is modulo 2^32).  The reference's `if(seed == 0) seed = 1` follows a
+// signed square whose overflow is undefined; the OpenCL compilers it meets (LLVM: verified in the gfx950 code object) test
+// the un-squared index instead, so a square that wraps to 0 leaves the seed 0 - and every random number of that path 0.
 __device__ __forceinline__ int lcg_seed(uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration)
 {
-    uint32_t s = gx + gy * w + iteration * w * h;
-    s *= 2011u;
+    const uint32_t index = gx + gy * w + iteration * w * h;
+    uint32_t s = index * 2011u;
     s *= s;
-    return (int)(s == 0u ? 1u : s);
+    return (int)(index == 0u ? 1u : s);
 }
 
 // Vector_PutInSameHemisphereAs, header.cl:237-244

@@ -109,6 +109,11 @@ float pto_fresnel_glass(const float incident[4], const float n[4]);
 float pto_fresnel_varnish(const float incident[4], const float n[4]);
 void pto_sky_color(const ptmi_sky* sky, const ptmi_uchar4* textures_data, const float direction[4], float rgba[4]);
 void pto_sincos(float x, float* s, float* c);
+/* normalize()'s reciprocal square root is the hardware instruction of the platform the reference runs on: its deviations
+ * from the correctly rounded value come from a table measured on that hardware (2^24 entries x 2 bits, see pt_oracle.c).
+ * Must be set before anything that normalises a vector is called. */
+void pto_set_rsq_table(const uint8_t* packed);
+float pto_hardware_rsq(float x);
 
 #ifdef __cplusplus
 }

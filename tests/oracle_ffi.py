@@ -56,6 +56,7 @@ class PtoBounce(C.Structure):
 
 
 _oracle = None
+_rsq_table = None  # kept alive: the oracle holds a pointer into it
 
 
 def build_oracle():
@@ -95,6 +96,17 @@ def oracle():
         lib.pto_sky_color.restype = None
         lib.pto_cosine_sample_hemisphere.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.pto_cosine_sample_hemisphere.restype = None
+        # normalize()'s reciprocal square root on the platform the reference runs on is a hardware instruction: the
+        # oracle reproduces it from the table measured on an MI355X (tests/golden/make_rsq_table.py)
+        global _rsq_table
+        _rsq_table = np.ascontiguousarray(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                               "rsq_gfx950.npz"))["packed"])
+        assert _rsq_table.dtype == np.uint8 and _rsq_table.size == 1 << 22
+        lib.pto_set_rsq_table.argtypes = [C.c_void_p]
+        lib.pto_set_rsq_table.restype = None
+        lib.pto_set_rsq_table(_rsq_table.ctypes.data_as(C.c_void_p))
+        lib.pto_hardware_rsq.argtypes = [C.c_float]
+        lib.pto_hardware_rsq.restype = C.c_float
         _oracle = lib
     return _oracle
 

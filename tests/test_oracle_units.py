@@ -17,10 +17,11 @@ def _arr4(v):
 
 def py_seed(x, y, w, h, it):
     # header.cl:255-264, int32 wrap-around
-    s = (x + y * w + it * w * h) & 0xFFFFFFFF
-    s = (s * 2011) & 0xFFFFFFFF
+    # the zero test is on the un-squared index (what LLVM makes of the signed square, see pt_oracle.c)
+    index = (x + y * w + it * w * h) & 0xFFFFFFFF
+    s = (index * 2011) & 0xFFFFFFFF
     s = (s * s) & 0xFFFFFFFF
-    s = s or 1
+    s = s if index else 1
     return s - (1 << 32) if s & 0x80000000 else s
 
 
@@ -33,7 +34,7 @@ def py_random(seed):
 def test_rng_known_answers(built):
     lib = O.oracle()
     for (x, y, w, h, it) in [(0, 0, 64, 48, 0), (1, 0, 64, 48, 0), (63, 47, 64, 48, 7), (1919, 1079, 1920, 1080, 255),
-                             (5, 9, 1920, 1080, 4095), (0, 0, 1, 1, 0)]:
+                             (5, 9, 1920, 1080, 4095), (0, 0, 1, 1, 0), (64, 42, 96, 96, 28), (0, 0, 256, 256, 1)]:
         s = lib.pto_initialize_random_seed(x, y, w, h, it)
         assert s == py_seed(x, y, w, h, it)
         cs, ps = C.c_int32(s), s
