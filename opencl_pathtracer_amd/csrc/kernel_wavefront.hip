@@ -76,7 +76,8 @@ constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 // instead of the point - path logic rebuilds the point from the ray it still holds with the very operations of the
 // triangle test, bit for bit - s, t, and one word triangle | front | found.  LDS per workgroup = (tree depth + 1 + words)
 // KB: with 4 words trees up to depth 27 keep five workgroups per CU (8 words: up to depth 22; the 4M-triangle scene is 24).
-#define PTMI_WF_HIT_WORDS 8
+// Measured on MI355X, same box, 1M triangles 1080p: 4 words 759-761, 8 words 751-753 Msamples/s.
+#define PTMI_WF_HIT_WORDS 4
 #endif
 constexpr int kHitWords = PTMI_WF_HIT_WORDS;
 static_assert(kHitWords == 4 || kHitWords == 8, "closest-hit record: 4 or 8 words");

@@ -16,6 +16,19 @@ CASES = {
 }
 SMALL = [k for k in CASES if not k.startswith("tris1m")]
 FIXTURE_RANGES = [(0, 8), (8, 8)]  # (first iteration, count): two shards of a 16-spp render
+STRICT_SPP = 4                      # iterations 0..3 of the reference's strict build are stored in full (bit-exact pin)
+FEATURE_CASE = ("feat_64x64_d8", 64, 64, 8)  # one specialisation of the reference kernel for every scenes.feature_scene
+FEATURE_SPP = 8
+
+
+def result_digest(color, count, depths, bbx, tri):
+    """SHA-256 over the bits of a render: image, sample counts and the three histograms."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for a, t in ((color, np.float32), (count, np.float32), (depths, np.uint32), (bbx, np.uint32), (tri, np.uint32)):
+        h.update(np.ascontiguousarray(a, dtype=t).tobytes())
+    return h.hexdigest()
 
 
 def rms_per_channel(a_color, a_count, b_color, b_count):

@@ -61,9 +61,27 @@ def main(out_dir):
             out["strict_16spp_work"] = np.array([(s_bbx.astype(np.int64) * k).sum(), (s_tri.astype(np.int64) * k).sum()])
             out["strict_16spp_depths"] = s_dep
             out["strict_16spp_color_mean"] = s_color[..., :3].mean(axis=(0, 1))
+            # (c) the strict build's outputs themselves, iterations 0..3: the oracle and the integrator follow the same
+            # arithmetic (IEEE operations + the platform library's dot / normalize / sin / cos) and must equal them bit for bit
+            e_color, e_count, (e_dep, e_bbx, e_tri), _ = O.ref_gpu_render(case, sc, w, h, d, cases.STRICT_SPP, strict=True)
+            out["strict_exact_color"], out["strict_exact_count"], out["strict_exact_depths"] = e_color, e_count, e_dep
+            nzb, nzt = np.flatnonzero(e_bbx), np.flatnonzero(e_tri)
+            out["strict_exact_bbx_idx"], out["strict_exact_bbx_val"] = nzb.astype(np.uint16), e_bbx[nzb]
+            out["strict_exact_tri_idx"], out["strict_exact_tri_val"] = nzt.astype(np.uint16), e_tri[nzt]
         one, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1)
         out["it0_1_color"] = one
         np.savez_compressed(os.path.join(out_dir, f"ref_{case}.npz"), **out)
+    # one kernel feature per scene through the strict build: digests of image, counts and histograms (8 spp each)
+    fcase, fw, fh, fd = cases.FEATURE_CASE
+    if O.have_ref_kernel(fcase, strict=True):
+        digests = {}
+        for feature in scenes.FEATURES:
+            sc = bvh_create(scenes.build("feat_" + feature, fw, fh))
+            color, count, (dep, bbx, tri), _ = O.ref_gpu_render(fcase, sc, fw, fh, fd, cases.FEATURE_SPP, strict=True)
+            digests[feature] = cases.result_digest(color, count, dep, bbx, tri)
+            digests[feature + "_scene"] = scene_digest(sc)
+            print("feature", feature, digests[feature][:16], flush=True)
+        np.savez_compressed(os.path.join(out_dir, f"ref_{fcase}_features.npz"), **{k: np.array(v) for k, v in digests.items()})
 
 
 if __name__ == "__main__":

@@ -81,3 +81,43 @@ def test_oracle_matches_reference_fixture(case, scene_factory):
     calibrated = rms <= max(2e-4, 3 * floor)
     few_flips = rep["n_flipped"] <= max(3, 0.005 * rep["n_pixels"]) and rep["rms_without_flipped"] <= 1e-4
     assert calibrated or few_flips, (rms, floor, rep)
+
+
+@pytest.mark.parametrize("case", list(cases.CASES))
+def test_oracle_equals_the_reference_strict_build(case, scene_factory):
+    """Bit for bit: image, sample counts and histograms of iterations 0..3 as the reference's STRICT build produced them on
+    the MI355X (fixtures `strict_exact_*`).  The oracle's arithmetic is that build's: IEEE operations in the written order
+    plus the platform library's dot / cross / normalize (v_rsq_f32 through the measured table) / sin / cos."""
+    fx = np.load(os.path.join(GOLDEN, f"ref_{case}.npz"))
+    if "strict_exact_color" not in fx:
+        pytest.skip("fixture predates the strict-build images")
+    name, sampler, w, h, d = cases.CASES[case]
+    if name == "tris1m" and os.environ.get("PTMI_SKIP_SLOW"):
+        pytest.skip("slow")
+    sc = scene_factory(name, w, h)
+    color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.STRICT_SPP, sampler=sampler)
+    assert np.array_equal(count, fx["strict_exact_count"]) and np.array_equal(dep, fx["strict_exact_depths"])
+    assert np.array_equal(bbx.astype(np.int64), _expand(fx["strict_exact_bbx_idx"], fx["strict_exact_bbx_val"]))
+    assert np.array_equal(tri.astype(np.int64), _expand(fx["strict_exact_tri_idx"], fx["strict_exact_tri_val"]))
+    bad = np.argwhere(color.view(np.uint32) != fx["strict_exact_color"].view(np.uint32))
+    assert len(bad) == 0, f"{len(bad)} channel values differ from the reference's strict build, first at {bad[:5].tolist()}"
+
+
+def test_oracle_equals_the_reference_strict_build_feature_by_feature(built):
+    """Every material branch, light type, texture path and the cube-map sky, one per scene: SHA-256 of the oracle's result
+    equals the digest of the reference's strict build (tests/golden/ref_feat_64x64_d8_features.npz)."""
+    from opencl_pathtracer_amd import scenes, bvh_create
+    import importlib.util
+    fcase, w, h, d = cases.FEATURE_CASE
+    path = os.path.join(GOLDEN, f"ref_{fcase}_features.npz")
+    if not os.path.exists(path):
+        pytest.skip("feature fixture not generated yet")
+    fx = np.load(path)
+    spec = importlib.util.spec_from_file_location("mkfx", os.path.join(GOLDEN, "make_reference_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for feature in scenes.FEATURES:
+        sc = bvh_create(scenes.build("feat_" + feature, w, h))
+        assert str(fx[feature + "_scene"]) == mk.scene_digest(sc), "scene generator changed since the fixture was made"
+        color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.FEATURE_SPP)
+        assert cases.result_digest(color, count, dep, bbx, tri) == str(fx[feature]), feature
