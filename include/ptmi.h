@@ -32,7 +32,7 @@ extern "C" {
 
 #define PTMI_ABI_VERSION 2
 #define PTMI_MAX_DEVICES 16       /* devices that can share one render */
-#define PTMI_MAX_SNAPSHOT_SLOTS 16 /* ptmi_snapshot ring */
+#define PTMI_MAX_SNAPSHOT_SLOTS 33 /* ptmi_snapshot ring: slots 0..31 are the caller's, the last one the library's own */
 
 typedef enum ptmi_status {
     PTMI_OK = 0,
@@ -159,8 +159,14 @@ int ptmi_unpin_host_buffer(ptmi_ctx* ctx, void* buffer);
  *   ptmi_read_snapshot(slot)  waits for that copy only (not for launches queued after it), sums the devices'
  *                             partial images on devices[0], copies the result to the host buffers; with both
  *                             pointers NULL it only waits until the snapshot has been taken (clFinish of that image).
- * Loop of a viewer: render(k+1); read_snapshot(k); show; snapshot(k+1) ...  (csrc/PathTracer_HIP.cpp). */
+ * Loop of a viewer: render(k+1); read_snapshot(k); show; snapshot(k+1) ...  (csrc/PathTracer_HIP.cpp).
+ *   ptmi_render_snapshots(first, n, first_slot)   ptmi_render(first, n) that ALSO leaves a snapshot after every one of
+ *                             its n iterations - iteration first + k in slot (first_slot + k) % (PTMI_MAX_SNAPSHOT_SLOTS - 1)
+ *                             - although the iterations share kernel launches: a viewer still gets every image of the
+ *                             reference's launch-per-image loop, at the throughput of n iterations per launch.
+ *                             n < PTMI_MAX_SNAPSHOT_SLOTS; JITTERED / UNIFORM sampler, wavefront kernel, no super_sampling. */
 int ptmi_snapshot(ptmi_ctx* ctx, uint32_t slot);
+int ptmi_render_snapshots(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations, uint32_t first_slot);
 int ptmi_read_snapshot(ptmi_ctx* ctx, uint32_t slot, float* image_color, float* image_ray_nb);
 
 /* The inverse of ptmi_read_image: load the accumulators (e.g. to resume a render saved earlier, or to accumulate on top of

@@ -82,7 +82,7 @@ FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront ker
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
@@ -109,6 +109,7 @@ def load_library():
     lib.ptmi_read_image.argtypes = [vp, vp, vp]
     lib.ptmi_read_display.argtypes = [vp, vp, u32]
     lib.ptmi_snapshot.argtypes = [vp, u32]
+    lib.ptmi_render_snapshots.argtypes = [vp, u32, u32, u32]
     lib.ptmi_pin_host_buffer.argtypes = [vp, vp, C.c_size_t]
     lib.ptmi_unpin_host_buffer.argtypes = [vp, vp]
     lib.ptmi_read_snapshot.argtypes = [vp, u32, vp, vp]
@@ -255,6 +256,10 @@ class Backend:
     def snapshot(self, slot=0):
         """Queue a device-side copy of the accumulators behind the launches issued so far (ptmi_snapshot)."""
         self._check(self._lib.ptmi_snapshot(self._ctx, slot))
+
+    def render_snapshots(self, first_iteration, n_iterations, first_slot=0):
+        """render() that also leaves a snapshot after each of its iterations (slots first_slot, first_slot + 1, ...)."""
+        self._check(self._lib.ptmi_render_snapshots(self._ctx, first_iteration, n_iterations, first_slot))
 
     def read_snapshot(self, slot=0, out=None):
         """Wait for snapshot ``slot`` only and return it; ``out`` = (color, count) arrays to fill (DMA'd into directly

@@ -37,9 +37,12 @@
 //
 // Environment knobs (all optional):
 //   PTMI_DEVICES = "all" (default) or a comma-separated list of HIP ordinals;  PTMI_DEVICE = one ordinal (wins)
-//   PTMI_IMAGES_PER_LAUNCH = images rendered per step and per callback (default 1 = the reference's behaviour)
-//   PTMI_LOOKAHEAD = steps queued ahead of the one being read back (default max(2, devices); 0 = the reference's
-//                    launch / wait / read / callback sequence)
+//   PTMI_BURST = images that share one kernel launch while EACH still gets its readback and callback, in order (default 8:
+//                the viewer sees every image of the reference's loop, in bursts, at the throughput of 8 images per launch;
+//                1 = one launch per image)
+//   PTMI_IMAGES_PER_LAUNCH = images rendered per step AND per callback (default 1 = the reference's count of callbacks)
+//   PTMI_LOOKAHEAD = steps queued ahead of the one being read back when PTMI_BURST is 1 (default max(2, devices); 0 = the
+//                    reference's launch / wait / read / callback sequence)
 //   PTMI_LOG = 1 (or globalVars.printLogInfos, the reference's -D LOG_INFO switch, OpenCL.cpp:310): one line per step
 //              on stderr with the iteration range and the three timers
 #ifdef PTMI_USE_REFERENCE_HEADERS
@@ -75,6 +78,11 @@ bool g_log = false;
     }
     throw std::runtime_error(msg);
 }
+
+// the samplers whose samples land on the work-item's own pixel (FullKernel.cl:1119-1150): launches of several iterations are
+// staged per iteration and can be snapshotted one by one; also no adaptive sampling (its launches are one iteration anyway)
+bool g_staged = true;
+bool sampler_owns_pixels(const GlobalVars&) { return g_staged; }
 
 unsigned env_uint(const char* name, unsigned fallback)
 {
@@ -123,6 +131,7 @@ void OpenCL_SetupContext(GlobalVars& globalVars, Sampler sampler)
     cfg.lights_size = globalVars.lightsSize;
     cfg.sampler = sampler == RANDOM ? PTMI_SAMPLER_RANDOM : (sampler == UNIFORM ? PTMI_SAMPLER_UNIFORM : PTMI_SAMPLER_JITTERED);
     cfg.super_sampling = globalVars.superSampling ? 1u : 0u;
+    g_staged = sampler != RANDOM && !globalVars.superSampling;
     cfg.flags = 0;
     const int rc = ptmi_setup_context(&g_ctx, &cfg);
     if (rc) fail("OpenCL_SetupContext", rc);
@@ -170,6 +179,53 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
     // is one DMA (best effort: a buffer that cannot be locked goes through the library's staging buffer)
     (void)ptmi_pin_host_buffer(g_ctx, globalVars.imageColor, sizeof(RGBAColor) * (size_t)globalVars.imageWidth * globalVars.imageHeight);
     (void)ptmi_pin_host_buffer(g_ctx, globalVars.imageRayNb, sizeof(float) * (size_t)globalVars.imageWidth * globalVars.imageHeight);
+    auto show = [&](uint slot, uint first_image, uint last_image, double t_path) {  // read image `slot` back, call the viewer
+        std::clock_t start = std::clock();
+        int rc = ptmi_read_snapshot(g_ctx, slot, reinterpret_cast<float*>(globalVars.imageColor), globalVars.imageRayNb);
+        if (rc) fail("OpenCL_RunKernel (readback)", rc);
+        const double t_mem = (double)(std::clock() - start);
+        *memoryTime += t_mem;
+        start = std::clock();
+        if (UpdateWindowFunc) (*UpdateWindowFunc)();  // return value ignored, as in OpenCL.cpp:103
+        const double t_disp = (double)(std::clock() - start);
+        *displayTime += t_disp;
+        if (g_log)
+            std::fprintf(stderr, "[ptmi] images %u..%u of %u on %u device(s): wait %.0f, readback %.0f, display %.0f clock ticks\n", first_image,
+                         last_image, numImagesToRender, g_devices, t_path, t_mem, t_disp);
+    };
+    // ---- bursts: B images per launch, a snapshot behind every one of them (ptmi_render_snapshots), one burst queued ahead
+    unsigned burst = env_uint("PTMI_BURST", 8);
+    const unsigned ring = PTMI_MAX_SNAPSHOT_SLOTS - 1;
+    if (burst > ring / 2) burst = ring / 2;
+    if (batch == 1 && burst > 1 && sampler_owns_pixels(globalVars)) {
+        const uint bursts = (numImagesToRender + burst - 1) / burst;
+        auto enqueue_burst = [&](uint b) {
+            const uint first = b * burst;
+            const uint n = numImagesToRender - first < burst ? numImagesToRender - first : burst;
+            const int rc = ptmi_render_snapshots(g_ctx, first, n, first % ring);
+            if (rc) fail("OpenCL_RunKernel (launch)", rc);
+        };
+        uint queued = 0;
+        for (uint b = 0; b < bursts; b++) {
+            std::clock_t start = std::clock();
+            while (queued < bursts && queued <= b + 1) enqueue_burst(queued++);
+            const uint first = b * burst;
+            const uint n = numImagesToRender - first < burst ? numImagesToRender - first : burst;
+            for (uint k = 0; k < n; k++) {
+                const int rc = ptmi_read_snapshot(g_ctx, (first + k) % ring, nullptr, nullptr);  // clFinish of that image
+                if (rc) fail("OpenCL_RunKernel (wait)", rc);
+                const double t_path = (double)(std::clock() - start);
+                *pathTracingTime += t_path;
+                show((first + k) % ring, first + k, first + k, t_path);
+                start = std::clock();
+            }
+        }
+        const int rc = ptmi_read_statistics(g_ctx, globalVars.rayDepths, globalVars.rayIntersectedBBx, globalVars.rayIntersectedTri);
+        if (rc) fail("OpenCL_RunKernel (statistics)", rc);
+        ptmi_release(g_ctx);
+        g_ctx = nullptr;
+        return;
+    }
     const uint steps = (numImagesToRender + batch - 1) / batch;
     // step s = images [s * batch, min((s + 1) * batch, numImagesToRender)): launch(es) + a snapshot behind them
     auto enqueue = [&](uint s) {
@@ -188,20 +244,7 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
         const double t_path = (double)(std::clock() - start);
         *pathTracingTime += t_path;
 
-        start = std::clock();
-        rc = ptmi_read_snapshot(g_ctx, s % slots, reinterpret_cast<float*>(globalVars.imageColor), globalVars.imageRayNb);
-        if (rc) fail("OpenCL_RunKernel (readback)", rc);
-        const double t_mem = (double)(std::clock() - start);
-        *memoryTime += t_mem;
-
-        start = std::clock();
-        if (UpdateWindowFunc) (*UpdateWindowFunc)();  // return value ignored, as in OpenCL.cpp:103
-        const double t_disp = (double)(std::clock() - start);
-        *displayTime += t_disp;
-        if (g_log)
-            std::fprintf(stderr, "[ptmi] images %u..%u of %u on %u device(s): wait %.0f, readback %.0f, display %.0f clock ticks\n", s * batch,
-                         (s + 1) * batch < numImagesToRender ? (s + 1) * batch - 1 : numImagesToRender - 1, numImagesToRender, g_devices,
-                         t_path, t_mem, t_disp);
+        show(s % slots, s * batch, (s + 1) * batch < numImagesToRender ? (s + 1) * batch - 1 : numImagesToRender - 1, t_path);
     }
     const int rc = ptmi_read_statistics(g_ctx, globalVars.rayDepths, globalVars.rayIntersectedBBx, globalVars.rayIntersectedTri);
     if (rc) fail("OpenCL_RunKernel (statistics)", rc);

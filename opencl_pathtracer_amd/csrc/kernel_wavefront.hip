@@ -763,7 +763,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
 // in iteration order) and the staged statistics words into the three histograms.  May run on another stream than the
 // launch (the caller orders them with an event): these two small kernels are what keeps launches in iteration order.
 int launch_accumulate_staged(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,
-                             const uint32_t* stage_stats, void* stream, std::string* err)
+                             const uint32_t* stage_stats, bool with_histograms, void* stream, std::string* err)
 {
     if (n_iterations == 0 || sc.sampler == PTMI_SAMPLER_RANDOM) return PTMI_OK;
     const uint32_t n_pixels = sc.width * sc.height;
@@ -773,16 +773,26 @@ int launch_accumulate_staged(const DScene& sc, uint32_t first_iteration, uint32_
     else
         hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
                            (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
-    if (stage_stats != nullptr) {  // the launch's paths into the three histograms
-        const uint32_t n_slots = n_pixels * n_iterations;
-        uint32_t hb = (n_slots + 1023u) / 1024u;
-        if (hb > 512u) hb = 512u;
-        hipLaunchKernelGGL(ptmi_dev::histogram_staged_kernel, dim3(hb), dim3(1024), 0, (hipStream_t)stream, sc.hist_depths,
-                           sc.hist_bbx, sc.hist_tri, stage_stats, sc.super_sampling ? sc.stage_flag : nullptr, n_slots);
-    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("accumulate_staged_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    if (with_histograms && stage_stats != nullptr) return launch_histogram_staged(sc, n_iterations, stage_stats, stream, err);
+    return PTMI_OK;
+}
+
+// the staged statistics words of `n_iterations` iterations into the three histograms
+int launch_histogram_staged(const DScene& sc, uint32_t n_iterations, const uint32_t* stage_stats, void* stream, std::string* err)
+{
+    const uint32_t n_slots = sc.width * sc.height * n_iterations;
+    uint32_t hb = (n_slots + 1023u) / 1024u;
+    if (hb > 512u) hb = 512u;
+    hipLaunchKernelGGL(ptmi_dev::histogram_staged_kernel, dim3(hb), dim3(1024), 0, (hipStream_t)stream, sc.hist_depths,
+                       sc.hist_bbx, sc.hist_tri, stage_stats, sc.super_sampling ? sc.stage_flag : nullptr, n_slots);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("histogram_staged_kernel launch: ") + hipGetErrorString(e);
         return PTMI_ERR_HIP;
     }
     return PTMI_OK;

@@ -475,10 +475,48 @@ void device_share(uint32_t first, uint32_t n, uint32_t k, uint32_t G, uint32_t* 
     *n_k = skip < n ? (n - skip + G - 1) / G : 0;
 }
 
-// One device's launches for its share of a ptmi_render call, bracketed by an event pair for ptmi_kernel_time.
-int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, uint32_t stride)
+// Queue, behind everything device `d` has been given so far, a copy of its accumulators into ring slot `slot`.
+int snapshot_device(ptmi_ctx* ctx, DeviceState& d, uint32_t slot)
 {
-    if (n == 0) return PTMI_OK;
+    const size_t npix = ctx->npix();
+    ON_DEVICE(ctx, d);
+    if (!d.d_snapshot[slot]) {
+        void* p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, npix * 20));
+        d.d_snapshot[slot] = (float*)p;
+    }
+    if (!d.snapshot_ready[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.snapshot_ready[slot], hipEventDisableTiming));
+    HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot], d.ds.image_color, npix * 16, hipMemcpyDeviceToDevice, d.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot] + 4 * npix, d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToDevice, d.stream));
+    HIP_TRY(ctx, hipEventRecord(d.snapshot_ready[slot], d.stream));
+    return PTMI_OK;
+}
+int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
+{
+    for (DeviceState& d : ctx->dev)
+        if (int rc = snapshot_device(ctx, d, slot)) return rc;
+    return PTMI_OK;
+}
+
+// ptmi_render_snapshots: a snapshot after EVERY iteration of the call although the iterations share launches.  Global
+// iteration first + k (k < n) goes to slot (first_slot + k) % PTMI_MAX_USER_SLOTS; a device snapshots for every k, with
+// whatever it has accumulated by then (its own ids up to first + k).
+struct SnapshotPlan {
+    uint32_t first, n, first_slot;
+    uint32_t next = 0;  // next global k to snapshot on this device
+};
+constexpr uint32_t kUserSlots = PTMI_MAX_SNAPSHOT_SLOTS - 1;  // the last slot is the library's own
+int snapshots_up_to(ptmi_ctx* ctx, DeviceState& d, SnapshotPlan& plan, uint32_t k_end)
+{
+    for (; plan.next < k_end && plan.next < plan.n; plan.next++)
+        if (int rc = snapshot_device(ctx, d, (plan.first_slot + plan.next) % kUserSlots)) return rc;
+    return PTMI_OK;
+}
+
+// One device's launches for its share of a ptmi_render call, bracketed by an event pair for ptmi_kernel_time.
+int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, uint32_t stride, SnapshotPlan* plan = nullptr)
+{
+    if (n == 0) return plan ? snapshots_up_to(ctx, d, *plan, plan->n) : PTMI_OK;
     ON_DEVICE(ctx, d);
     if (d.pending_events.size() >= 512)
         if (int rc = fold_events(ctx, d)) return rc;
@@ -558,7 +596,22 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     if (e == hipSuccess) e = hipStreamWaitEvent(d.stream, d.rendered[set], 0);
                     if (e != hipSuccess) break;
                 }
-                rc = launch_accumulate_staged(d.ds, first + done * stride, m, stage, stage_stats, d.stream, &err);
+                if (!plan) {
+                    rc = launch_accumulate_staged(d.ds, first + done * stride, m, stage, stage_stats, true, d.stream, &err);
+                } else {
+                    // one accumulation per iteration, each followed by the snapshots of the global iterations up to it
+                    for (uint32_t j = 0; j < m && rc == PTMI_OK; j++) {
+                        const uint32_t id = first + (done + j) * stride;
+                        rc = snapshots_up_to(ctx, d, *plan, id - plan->first);  // images before this device's next own one
+                        if (rc != PTMI_OK) break;
+                        rc = launch_accumulate_staged(d.ds, id, 1, stage + (size_t)j * npix * 4, stage_stats ? stage_stats + (size_t)j * npix : nullptr,
+                                                      false, d.stream, &err);
+                        if (rc == PTMI_OK) rc = snapshots_up_to(ctx, d, *plan, id - plan->first + 1);
+                    }
+                    if (rc == PTMI_OK && stage_stats)
+                        rc = launch_histogram_staged(d.ds, m, stage_stats, d.stream, &err);
+                    if (rc != PTMI_OK && err.empty()) err = ctx->err;
+                }
                 if (rc != PTMI_OK) break;
                 if (overlap) {
                     e = hipEventRecord(d.stage_free[set], d.stream);
@@ -568,6 +621,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 done += m;
             }
         }
+        if (e == hipSuccess && rc == PTMI_OK && plan) rc = snapshots_up_to(ctx, d, *plan, plan->n);  // images after its last own one
         if (e == hipSuccess) e = hipEventRecord(ev.second, d.stream);
     }
     if (e != hipSuccess || rc != PTMI_OK) {
@@ -613,25 +667,6 @@ int copy_out(ptmi_ctx* ctx, hipStream_t stream, const float* d_color, const floa
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (image_color && !pin_c) std::memcpy(image_color, ctx->h_staging, npix * 16);
     if (image_ray_nb && !pin_n) std::memcpy(image_ray_nb, ctx->h_staging + 4 * npix, npix * 4);
-    return PTMI_OK;
-}
-
-// Queue, behind everything each device has been given so far, a copy of its accumulators into ring slot `slot`.
-int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
-{
-    const size_t npix = ctx->npix();
-    for (DeviceState& d : ctx->dev) {
-        ON_DEVICE(ctx, d);
-        if (!d.d_snapshot[slot]) {
-            void* p = nullptr;
-            HIP_TRY(ctx, hipMalloc(&p, npix * 20));
-            d.d_snapshot[slot] = (float*)p;
-        }
-        if (!d.snapshot_ready[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.snapshot_ready[slot], hipEventDisableTiming));
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot], d.ds.image_color, npix * 16, hipMemcpyDeviceToDevice, d.stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot] + 4 * npix, d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToDevice, d.stream));
-        HIP_TRY(ctx, hipEventRecord(d.snapshot_ready[slot], d.stream));
-    }
     return PTMI_OK;
 }
 
@@ -684,6 +719,7 @@ int gather_snapshot(ptmi_ctx* ctx, uint32_t slot, const float** image)
 }
 
 constexpr uint32_t kInternalSlot = PTMI_MAX_SNAPSHOT_SLOTS - 1;  // ptmi_read_image / ptmi_read_display of a multi-device context
+static_assert(kInternalSlot == kUserSlots, "the library's own slot lies behind the callers'");
 
 }  // namespace
 
@@ -853,6 +889,28 @@ int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations)
     return PTMI_OK;
 }
 
+int ptmi_render_snapshots(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations, uint32_t first_slot)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_render_snapshots before ptmi_initialize_memory");
+    if (n_iterations == 0) return PTMI_OK;
+    if ((uint64_t)first_iteration + n_iterations > 0xFFFFFFFFull)
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "iteration range overflows 32 bits");
+    if (n_iterations > kUserSlots || first_slot >= kUserSlots)
+        return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "ptmi_render_snapshots: more iterations than snapshot slots, or slot out of range");
+    if (ctx->cfg.super_sampling || ctx->cfg.sampler == PTMI_SAMPLER_RANDOM || (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL))
+        return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_render_snapshots needs staged launches (JITTERED / UNIFORM sampler, wavefront kernel, no "
+                                                "super_sampling): call ptmi_render + ptmi_snapshot per iteration instead");
+    const uint32_t G = ctx->n_dev();
+    for (uint32_t k = 0; k < G; k++) {
+        uint32_t first_k, n_k;
+        device_share(first_iteration, n_iterations, k, G, &first_k, &n_k);
+        SnapshotPlan plan{first_iteration, n_iterations, first_slot};
+        if (int rc = render_on_device(ctx, ctx->dev[k], first_k, n_k, G, &plan)) return rc;
+    }
+    return PTMI_OK;
+}
+
 int ptmi_synchronize(ptmi_ctx* ctx)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
@@ -867,7 +925,7 @@ int ptmi_snapshot(ptmi_ctx* ctx, uint32_t slot)
 {
     if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_snapshot before ptmi_initialize_memory");
-    if (slot >= PTMI_MAX_SNAPSHOT_SLOTS) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "snapshot slot out of range");
+    if (slot >= kUserSlots) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "snapshot slot out of range");
     return snapshot_all(ctx, slot);
 }
 

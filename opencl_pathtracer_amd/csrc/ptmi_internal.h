@@ -146,7 +146,8 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
 // stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself)
 // ... and what must follow it, in launch order: staged radiances -> accumulators, staged statistics -> histograms
 int launch_accumulate_staged(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,
-                             const uint32_t* stage_stats, void* stream, std::string* err);
+                             const uint32_t* stage_stats, bool with_histograms, void* stream, std::string* err);
+int launch_histogram_staged(const DScene& sc, uint32_t n_iterations, const uint32_t* stage_stats, void* stream, std::string* err);
 
 // display.hip: accumulators -> padded B,G,R scanlines (the reference's ConvertRGBAToBMPBuffer), on the device
 int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint8_t* out, uint32_t width, uint32_t height,

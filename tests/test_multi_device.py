@@ -136,7 +136,7 @@ def test_snapshot_ring_equals_blocking_loop(devices, scene_factory):
     with pytest.raises(PtmiError):
         be.read_snapshot(slots + 1)  # never filled
     with pytest.raises(PtmiError):
-        be.snapshot(99)
+        be.snapshot(32)  # the library's own slot
     be.unpin_host_buffer(out[0])
     with pytest.raises(PtmiError):
         be.unpin_host_buffer(out[1])  # never pinned
@@ -162,3 +162,46 @@ def test_multi_device_bit_exact_parts_vs_oracle(scene_factory):
     color, count, _, _ = render_scene(sc, w, h, d, 6, devices=[0, 0])
     assert float(count.min()) == 6.0 == float(count.max())
     assert np.array_equal(color.view(np.uint32), expect.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
+def test_render_snapshots_leaves_every_image_of_the_per_image_loop(devices, scene_factory):
+    """ptmi_render_snapshots(first, n): iterations share launches (20 > 16 per launch: two chunks), yet slot k holds exactly
+    what the reference's loop would have read back after image first + k."""
+    w, h, d = 96, 64, 6
+    sc = scene_factory("tris20k", w, h)
+    first, n = 3, 20
+    blocking = Backend().setup_context(w, h, d, sc.lightsSize, devices=devices)
+    blocking.initialize_memory(sc)
+    blocking.render(0, first)
+    expect = []
+    for i in range(first, first + n):
+        blocking.render(i, 1)
+        c, cn = blocking.read_image()
+        expect.append((c.copy(), cn.copy()))
+    stats = blocking.read_statistics()
+    counters = blocking.counters()
+    blocking.release()
+
+    be = Backend().setup_context(w, h, d, sc.lightsSize, devices=devices)
+    be.initialize_memory(sc)
+    be.render(0, first)
+    be.render_snapshots(first, n, first_slot=30)  # wraps around the 32 caller slots
+    for k in range(n):
+        c, cn = be.read_snapshot((30 + k) % 32)
+        assert np.array_equal(cn, expect[k][1]), k
+        assert np.array_equal(c.view(np.uint32), expect[k][0].view(np.uint32)), k
+    s2 = be.read_statistics()
+    assert all(np.array_equal(a, b) for a, b in zip(stats, s2)) and be.counters() == counters
+    final, _ = be.read_image()
+    assert np.array_equal(final.view(np.uint32), expect[-1][0].view(np.uint32))
+    with pytest.raises(PtmiError):
+        be.render_snapshots(0, 33)
+    be.release()
+    rnd = Backend().setup_context(w, h, d, sc.lightsSize, sampler=S.RANDOM)
+    rnd.initialize_memory(sc)
+    with pytest.raises(PtmiError) as e:
+        rnd.render_snapshots(0, 2)
+    assert e.value.code == -7
+    rnd.release()

@@ -139,7 +139,8 @@ def test_reference_orchestration_links_and_reports_a_missing_device(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="oracle/_ref/ref_main_driver not built (needs the reference tree)")
-@pytest.mark.parametrize("env", [{}, {"PTMI_DEVICES": "0,0", "PTMI_LOOKAHEAD": "3"}, {"PTMI_LOOKAHEAD": "0"}])
+@pytest.mark.parametrize("env", [{}, {"PTMI_BURST": "4"}, {"PTMI_DEVICES": "0,0", "PTMI_BURST": "1", "PTMI_LOOKAHEAD": "3"},
+                                 {"PTMI_BURST": "1", "PTMI_LOOKAHEAD": "0"}, {"PTMI_DEVICES": "0,0,0"}])
 def test_reference_orchestration_renders(env, tmp_path):
     """PathTracer_Main -> BVH_Create -> OpenCL_SetupContext / InitializeMemory / RunKernel of the shim -> libptmi -> HIP
     kernels; the image the reference's window is handed after the last iteration equals the oracle's."""
