@@ -109,11 +109,10 @@ def main():
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)
     fb.bind(be)
-    # One explicit stream for the kernels AND the collective: the reduce must be ordered after the last
-    # launch.  (torch's default stream has handle 0, which ptmi_set_stream reads as "own stream".)
+    # The integrator keeps its own streams (consecutive launches alternate between two of them, so that the ramp-up of one
+    # fills the CUs the ragged end of the other leaves idle); the collective and the readback below run on a torch stream
+    # and are ordered behind the last launch by FusedAccumulators.reduce_to, which waits for the integrator first.
     stream = torch.cuda.Stream(device)
-    assert stream.cuda_stream != 0
-    be.set_stream(stream.cuda_stream)
     host_image = torch.empty(5 * W * H, dtype=torch.float32, pin_memory=True) if rank == 0 else None
 
     def step(s):
@@ -148,7 +147,7 @@ def main():
         dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
         fb.buffer.copy_(host)
     else:
-        fb.reduce_to(0, ordered=True)  # same stream as the launches; the one collective of a sharded render: RCCL reduce over xGMI (no-op at N=1)
+        fb.reduce_to(0)  # waits for this rank's launches, then the one collective of a sharded render: RCCL reduce over xGMI (no-op at N=1)
     if rank == 0:
         host_image.copy_(fb.buffer, non_blocking=True)  # t_render ends with the framebuffer on the host
     torch.cuda.synchronize(device)

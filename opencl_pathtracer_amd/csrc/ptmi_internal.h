@@ -158,6 +158,9 @@ int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint
 int launch_sum_images(float* out, const float* const* parts, uint32_t n_parts, size_t n_floats, void* stream, std::string* err);
 
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
-constexpr uint32_t kMaxIterationsPerLaunch = 16;
+#ifndef PTMI_MAX_ITERATIONS_PER_LAUNCH
+#define PTMI_MAX_ITERATIONS_PER_LAUNCH 16
+#endif
+constexpr uint32_t kMaxIterationsPerLaunch = PTMI_MAX_ITERATIONS_PER_LAUNCH;
 
 }  // namespace ptmi_internal

@@ -1,4 +1,3 @@
-python -m pytest tests -m gpu -q -x > gpurun_out/r02_t8_pytest.log 2>&1; tail -3 gpurun_out/r02_t8_pytest.log
-python bench.py --steps 6 --warmup 2 > gpurun_out/r02_bench_a.json 2> gpurun_out/r02_bench_a.err; cat gpurun_out/r02_bench_a.json
-PTMI_SERIAL_LAUNCHES=1 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r02_bench_a_serial.json 2> gpurun_out/r02_bench_a_serial.err; cat gpurun_out/r02_bench_a_serial.json
-python tools/time_reference_kernel.py tris1m_1920x1080_d10 2 > gpurun_out/r02_ref_tris1m.json 2>&1; cat gpurun_out/r02_ref_tris1m.json
+STEPS=3 BENCH_ARGS="--spp-per-step 32" bash tools/run_variants.sh it64 2>&1 | tee gpurun_out/r02_variants_d.log
+STEPS=2 BENCH_ARGS="--spp-per-step 64" bash tools/run_variants.sh it64 2>&1 | tee -a gpurun_out/r02_variants_d.log
+bash tools/run_variants.sh shortdiv 2>&1 | tee -a gpurun_out/r02_variants_d.log
