@@ -223,6 +223,7 @@ def main():
                                      for k in ("node", "triangle", "path")}
             tot = sum(sched["trips_" + k] for k in ("node", "triangle", "path"))
             out["wave_scheduler"]["trip_share"] = {k: round(sched["trips_" + k] / tot, 3) for k in ("node", "triangle", "path")}
+            out["wave_scheduler"]["wave_time_in_path_logic"] = round(sched["cycles_path"] / max(sched["cycles_loop"], 1), 3)
         if world == 1 and not args.no_boundary:
             out["boundary"] = boundary_loop(pt, scene, W, H, D, local_rank, flags, out["value"])
         if world == 1 and not args.no_cpu_baseline:

@@ -73,6 +73,10 @@ typedef struct ptmi_config {
 #define PTMI_FLAG_NO_HISTOGRAMS 1u /* skip the three per-path histogram atomics (FullKernel.cl:1319-1331); totals are still kept */
 #define PTMI_FLAG_SCHEDULER_STATS 4u /* collect ptmi_scheduler_stats (a few scalar ops per loop trip; off by default) */
 #define PTMI_FLAG_MEGAKERNEL 2u    /* one path per lane (kernels.hip) instead of the persistent wavefront kernel; same results */
+#define PTMI_FLAG_RUSSIAN_ROULETTE 8u /* NON-PARITY mode: the termination block the reference ships commented out (FullKernel.cl:1306-1314,
+                                         RUSSIAN_ROULETTE false in header.cl:12), as it is written there: from the 7th bounce on a path
+                                         whose largest transfer component / (bounce - 5) is below 1 draws a random number, ends unless it
+                                         exceeds that coefficient, and has its transfer divided by it.  Images differ from the reference's. */
 
 /* What OpenCL_InitializeMemory copies with CL_MEM_COPY_HOST_PTR and passes as
  * kernel arguments 1..17 (OpenCL.cpp:165-197).  Arrays are raw dumps of the
@@ -112,6 +116,7 @@ typedef struct ptmi_scheduler_stats {
     uint64_t trips_node, lanes_node;         /* inner-node steps */
     uint64_t trips_triangle, lanes_triangle; /* triangle tests */
     uint64_t trips_path, lanes_path;         /* path logic (shade / shadow set-up / scatter / regenerate) */
+    uint64_t cycles_path, cycles_loop;       /* shader-clock cycles, summed over waves: inside path-logic passes / in the main loop */
 } ptmi_scheduler_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */

@@ -70,7 +70,7 @@ class Counters(C.Structure):
 
 class SchedulerStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("trips_node", "lanes_node", "trips_triangle", "lanes_triangle", "trips_path",
-                                         "lanes_path")]
+                                         "lanes_path", "cycles_path", "cycles_loop")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -79,6 +79,7 @@ class SchedulerStats(C.Structure):
 FLAG_NO_HISTOGRAMS = 1
 FLAG_SCHEDULER_STATS = 4  # collect scheduler_stats() (off by default)
 FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)
+FLAG_RUSSIAN_ROULETTE = 8  # non-parity mode: the reference's commented-out termination block (FullKernel.cl:1306-1314)
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",

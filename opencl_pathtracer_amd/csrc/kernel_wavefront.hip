@@ -103,6 +103,7 @@ struct DWarm {
     uint32_t histograms;  // hist_depths != nullptr
     uint32_t boxes_ordered;
     uint32_t wide_records;  // the record array is 4 GB or more: 64-bit addressing
+    uint32_t russian_roulette;  // PTMI_FLAG_RUSSIAN_ROULETTE (non-parity mode)
 };
 
 // A finished path's three histogram bins in one word: depth (6 bits, < kStatDepthBins), box tests and triangle tests
@@ -216,6 +217,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // wave-uniform scheduler statistics (scalar registers): trips and active lanes per step kind
     uint32_t trips_i = 0, trips_t = 0, trips_p = 0;
     unsigned long long lanes_i = 0, lanes_t = 0, lanes_p = 0;
+    unsigned long long cycles_p = 0;
+    const unsigned long long loop_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // statistics + accumulation of a finished path (FullKernel.cl:1319-1345).  `missed`: the path ended on a sky miss,
     // i.e. it made one closest-hit query more than it has surface hits.
@@ -417,6 +420,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         wait_debt = 0;
         // ================================ P: path logic ========================================
         if (STATS) { trips_p++; lanes_p += n_p; }
+        const unsigned long long pass_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         // (three divergent regions with the wave-uniform job hand-out between them: the queue state must stay scalar)
         if (want_post) {
             need_path = cur == REF_IDLE;
@@ -465,9 +469,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
                         reflection++;
                         shadow = false;
-                        const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // :1296-1304
-                        const float m = transfer.x < m_yz ? m_yz : transfer.x;
-                        if (m <= kMinContribution || reflection >= sc.max_depth) {
+                        if (!path_continues(transfer, reflection, seed, sc.russian_roulette != 0) || reflection >= sc.max_depth) {  // :1296-1314, :1248
                             end_path = true;
                         } else {
                             limit = INFINITY;
@@ -580,6 +582,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
         }
         wave_exact = __builtin_amdgcn_ballot_w64(exact_boxes) != 0ull;  // finished lanes keep a stale flag: conservative
+        if (STATS) cycles_p += __builtin_amdgcn_s_memtime() - pass_start;
     }
 
     if (STATS && (tid & 63u) == 0) {  // one lane per wave: the scheduler counters are wave-uniform
@@ -589,6 +592,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         atomicAdd(&block_counters[C_LANES_T], lanes_t);
         atomicAdd(&block_counters[C_TRIPS_P], (unsigned long long)trips_p);
         atomicAdd(&block_counters[C_LANES_P], lanes_p);
+        atomicAdd(&block_counters[C_CYCLES_P], cycles_p);
+        atomicAdd(&block_counters[C_CYCLES_LOOP], __builtin_amdgcn_s_memtime() - loop_start);
     }
     __syncthreads();
     // every surface hit sends one shadow ray to every light (Scene_ComputeDirectIllumination, :901-954)
@@ -736,6 +741,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         warm.histograms = sc.hist_depths != nullptr;
         warm.boxes_ordered = sc.boxes_ordered;
         warm.wide_records = sc.wide_records;
+        warm.russian_roulette = sc.russian_roulette;
 #define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
     hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
                        first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)

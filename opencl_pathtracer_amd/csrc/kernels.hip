@@ -138,11 +138,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
             active = false;
             radiance = radiance + (sky_color(sc.sky, sc.texels, r.d) * transfer);  // :1281-1288
         }
-        if (active) {  // :1296-1304, OpenCL max(x, y) = x < y ? y : x
-            const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;
-            const float m = transfer.x < m_yz ? m_yz : transfer.x;
-            if (m <= kMinContribution) active = false;
-        }
+        if (active) active = path_continues(transfer, reflection, seed, sc.russian_roulette != 0);  // :1296-1314
     }
     depth = reflection;
     return radiance;

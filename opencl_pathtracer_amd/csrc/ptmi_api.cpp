@@ -463,6 +463,7 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     ds.max_depth = ctx->cfg.ray_max_depth;
     ds.n_lights = ctx->cfg.lights_size;
     ds.sampler = ctx->cfg.sampler;
+    ds.russian_roulette = (ctx->cfg.flags & PTMI_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u;
     HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
     return PTMI_OK;
 }
@@ -525,7 +526,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     // alternate launch streams: only where the launch itself neither reads nor writes the accumulators (staged results, no
     // adaptive sampling), on the context's own stream, and unless switched off (PTMI_SERIAL_LAUNCHES: developer A/B switch)
     static const bool serial_env = std::getenv("PTMI_SERIAL_LAUNCHES") != nullptr;
-    const bool overlap = staged && !ctx->cfg.super_sampling && d.stream == d.own_stream && !serial_env;
+    const bool may_overlap = staged && !ctx->cfg.super_sampling && d.stream == d.own_stream && !serial_env;
     const size_t npix = ctx->npix();
     if (staged) {
         // staging arrays for the launches: grow on demand, capped by iterations_per_launch
@@ -546,7 +547,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
             }
             d.stage_iterations = want;
         }
-        for (int i = 0; i < 2 && overlap; i++) {
+        for (int i = 0; i < 2 && may_overlap; i++) {
             if (!d.launch_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&d.launch_stream[i], hipStreamNonBlocking));
             if (!d.rendered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.rendered[i], hipEventDisableTiming));
             if (!d.stage_free[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.stage_free[i], hipEventDisableTiming));
@@ -577,6 +578,10 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
                 const uint32_t cap = ctx->cfg.super_sampling ? 1u : ctx->iterations_per_launch;
                 const uint32_t m = n - done < cap ? n - done : cap;
+                // Only SHORT launches alternate streams (measured on MI355X, 1M triangles 1080p: one image per launch 631 -> 657
+                // Msamples/s with the overlap; 16 images per launch 763 -> 753: two long persistent launches side by side only
+                // get in each other's way, and their ragged ends are 1 % of their length anyway)
+                const bool overlap = may_overlap && m < 4u;
                 const int set = overlap ? (int)(d.launches_issued & 1u) : 0;
                 hipStream_t ls = overlap ? d.launch_stream[set] : d.stream;
                 float* stage = staged ? d.d_stage[set] : nullptr;
@@ -585,7 +590,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 uint32_t* stage_stats = nullptr;
                 if (stage && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)
                     stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + d.stage_iterations * npix * 16);
-                if (overlap && d.stage_busy[set]) e = hipStreamWaitEvent(ls, d.stage_free[set], 0);
+                if (may_overlap && d.stage_busy[set]) e = hipStreamWaitEvent(ls, d.stage_free[set], 0);
                 if (e != hipSuccess) break;
                 rc = launch_render_wavefront(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter + set * 8 * 1024,
                                              d.resident_blocks, ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, stage,
@@ -613,7 +618,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     if (rc != PTMI_OK && err.empty()) err = ctx->err;
                 }
                 if (rc != PTMI_OK) break;
-                if (overlap) {
+                if (may_overlap) {  // (also behind a launch on the main stream: a later short launch may take this set)
                     e = hipEventRecord(d.stage_free[set], d.stream);
                     d.stage_busy[set] = true;
                 }
@@ -1101,6 +1106,7 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
     out->trips_node = h[C_TRIPS_I]; out->lanes_node = h[C_LANES_I];
     out->trips_triangle = h[C_TRIPS_T]; out->lanes_triangle = h[C_LANES_T];
     out->trips_path = h[C_TRIPS_P]; out->lanes_path = h[C_LANES_P];
+    out->cycles_path = h[C_CYCLES_P]; out->cycles_loop = h[C_CYCLES_LOOP];
     return PTMI_OK;
 }
 

@@ -94,6 +94,8 @@ enum CounterSlot {
     C_PATHS = 0, C_SEGMENTS, C_HITS, C_SHADOW, C_BBX, C_TRI,
     // wave scheduler of the wavefront kernel: loop trips and active lanes per step kind
     C_TRIPS_I, C_LANES_I, C_TRIPS_T, C_LANES_T, C_TRIPS_P, C_LANES_P,
+    // ... and where its waves spend their life: shader clock cycles inside path-logic passes / in the whole main loop
+    C_CYCLES_P, C_CYCLES_LOOP,
     C_COUNT
 };
 
@@ -129,6 +131,7 @@ struct DScene {
     uint32_t n_records;        // nodes + leaf triangles in the one record array (nodes == tris)
     uint32_t wide_records;     // that array is 4 GB or more: byte offsets need 64 bits
     uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)
+    uint32_t russian_roulette; // PTMI_FLAG_RUSSIAN_ROULETTE
 };
 
 // kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)

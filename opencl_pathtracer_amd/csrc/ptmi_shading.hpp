@@ -105,6 +105,24 @@ __device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const H
     return radiance;
 }
 
+// The end-of-bounce tests of Kernel_Main's loop (FullKernel.cl:1296-1314): false = the path ends here.  `russian_roulette`
+// enables the block the reference ships commented out (:1306-1314), evaluated as it is written there.
+__device__ __forceinline__ bool path_continues(V4& transfer, uint32_t reflection, int& seed, bool russian_roulette)
+{
+    const float m_yz = transfer.y < transfer.z ? transfer.z : transfer.y;  // OpenCL max(x, y) = x < y ? y : x
+    const float m = transfer.x < m_yz ? m_yz : transfer.x;
+    if (m <= kMinContribution) return false;
+    bool active = true;
+    if (russian_roulette && reflection > 5u) {  // MIN_REFLECTION_NUMBER, header.cl:13
+        const float coeff = m / (float)(reflection - 5u);
+        if (coeff < 1) {
+            active = lcg_random(seed) > coeff;
+            transfer = transfer / coeff;
+        }
+    }
+    return active;
+}
+
 // sampler(), FullKernel.cl:1119-1150
 template <class SceneT>
 __device__ __forceinline__ void draw_sample(const SceneT& sc, uint32_t gx, uint32_t gy, uint32_t iteration, int& seed,

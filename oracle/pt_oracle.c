@@ -783,6 +783,14 @@ static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint3
         if (active) { /* cl:1296-1304 */
             const float max_contribution = cl_max(transfer.x, cl_max(transfer.y, transfer.z));
             if (max_contribution <= MIN_CONTRIBUTION_VALUE) active = 0;
+            /* cl:1306-1314, commented out in the reference (RUSSIAN_ROULETTE false, h:12): as written there */
+            if (sc->russian_roulette && active && r.reflection_id > MIN_REFLECTION_NUMBER) {
+                const float coeff = max_contribution / (float)(r.reflection_id - MIN_REFLECTION_NUMBER);
+                if (coeff < 1) {
+                    active = active && (pto_random(&seed) > coeff);
+                    transfer = div4s(transfer, coeff);
+                }
+            }
         }
     }
 

@@ -220,3 +220,15 @@ def test_render_properties(built, scene_factory):
     # depth 0: no segment is traced, radiance 0, every path lands in bin 0
     c0, n0, (d0, _, _), t0 = O.oracle_render(sc, 96, 96, 0, 1)
     assert not c0.any() and (n0 == 1).all() and d0[0] == 96 * 96 and t0["segments"] == 0
+
+
+def test_russian_roulette_switch_of_the_oracle(scene_factory):
+    """cl:1306-1314 (commented out in the reference): off by default - the parity mode - and, when on, paths end from the
+    7th bounce on with the transfer function divided by the roulette coefficient."""
+    sc = scene_factory("cornell", 48, 32)
+    off, _, (d_off, _, _), t_off = O.oracle_render(sc, 48, 32, 16, 4)
+    on, _, (d_on, _, _), t_on = O.oracle_render(sc, 48, 32, 16, 4, russian_roulette=True)
+    assert d_off.sum() == d_on.sum() == 48 * 32 * 4
+    assert np.array_equal(d_off[:6], d_on[:6])          # nothing changes for paths of up to five bounces ...
+    assert d_on[6:16].sum() > d_off[6:16].sum() and d_on[16] < d_off[16]   # ... then paths end early
+    assert t_on["segments"] < t_off["segments"] and np.isfinite(on).all() and not np.array_equal(on, off)

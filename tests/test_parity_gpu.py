@@ -123,6 +123,22 @@ def test_degenerate_trees_and_big_leaves(kernel, scene_factory):
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
+def test_russian_roulette_mode_vs_oracle(kernel, scene_factory):
+    """PTMI_FLAG_RUSSIAN_ROULETTE: the termination block the reference ships commented out (FullKernel.cl:1306-1314), as
+    written there - a non-parity mode (images differ from the reference's), bit-exact against the oracle's same switch."""
+    from opencl_pathtracer_amd.backend import FLAG_RUSSIAN_ROULETTE
+    w, h, d = 64, 48, 16
+    sc = scene_factory("cornell", w, h)
+    color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, 6, flags=KERNELS[kernel] | FLAG_RUSSIAN_ROULETTE)
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, 6, russian_roulette=True)
+    assert counters == totals and np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
+    plain, _, (p_dep, _, _), _ = render_scene(sc, w, h, d, 6, flags=KERNELS[kernel])
+    assert dep[7:].sum() > 0 and dep[d] < p_dep[d]  # paths now end between the 7th bounce and the depth limit
+    assert not np.array_equal(color, plain)
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 def test_leaf_without_triangles_next_to_a_leaf(kernel, scene_factory):
     """A hand-made tree the product builder never emits: a leaf with nbTriangles == 0 whose box is NOT flagged isEmpty,
     sibling of an ordinary leaf.  The reference descends into it (its leaf loop runs zero times, FullKernel.cl:638-646)

@@ -1,3 +1,6 @@
-STEPS=3 BENCH_ARGS="--spp-per-step 32" bash tools/run_variants.sh it64 2>&1 | tee gpurun_out/r02_variants_d.log
-STEPS=2 BENCH_ARGS="--spp-per-step 64" bash tools/run_variants.sh it64 2>&1 | tee -a gpurun_out/r02_variants_d.log
-bash tools/run_variants.sh shortdiv 2>&1 | tee -a gpurun_out/r02_variants_d.log
+for i in 1 2; do
+python bench.py --scene cornell --depth 8 --steps 8 --warmup 2 --no-cpu-baseline --no-boundary > gpurun_out/r02_bench_e_cornell.json 2>>gpurun_out/r02_bench_e.err; python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_e_cornell.json')); print('cornell', d['value'], d['Mpaths/s'])"
+python bench.py --scene matmix --width 3840 --height 2160 --depth 16 --steps 3 --warmup 1 --no-cpu-baseline --no-boundary > gpurun_out/r02_bench_e_matmix.json 2>>gpurun_out/r02_bench_e.err; python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_e_matmix.json')); print('matmix4k', d['value'], d['Mpaths/s'])"
+done
