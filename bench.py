@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=16,
+    ap.add_argument("--spp-per-step", type=int, default=32,
                     help="iterations per step: per GPU (weak scaling, default) or for the whole job (--strong)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --spp-per-step ids per step are split over the ranks")
     ap.add_argument("--total-spp", type=int, default=0,
@@ -246,9 +246,11 @@ def committed_pmc(args, W, H, D, B):
     run, summarised by tools/summarize_pmc.py), committed as profiles/r02_pmc_<scene>.json.  bench.py itself cannot read
     PMC counters; the file is only used for the configuration it was measured on."""
     path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.scene}.json")
-    if not os.path.exists(path) or (W, H, D, B, args.kernel) != (1920, 1080, 10, 16, "wavefront"):
+    if not os.path.exists(path) or (W, H, D, args.kernel) != (1920, 1080, 10, "wavefront"):
         return None
     pmc = json.load(open(path))
+    if pmc.get("_spp_per_launch") != min(B, 32):  # counters are per launch: only comparable at the same launch size
+        return None
     pmc["_path"] = os.path.relpath(path, ROOT)
     return pmc
 
@@ -296,7 +298,7 @@ def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
     framebuffer read back into the viewer's buffers and a callback after EVERY image - through the same C ABI calls
     csrc/PathTracer_HIP.cpp makes.  Three variants: the reference's blocking sequence (launch, wait, read, callback),
     the shim's default (launches of the next two images queued while image k crosses the bus: ptmi_snapshot /
-    ptmi_read_snapshot into page-locked buffers), and 16 images per launch and callback (PTMI_IMAGES_PER_LAUNCH=16)."""
+    ptmi_read_snapshot into page-locked buffers), and 32 images per launch and callback (PTMI_IMAGES_PER_LAUNCH=32)."""
     import numpy as np
     be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=device, flags=flags)
     be.initialize_memory(scene)
@@ -347,13 +349,13 @@ def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
            "per_image_blocking_Msamples/s": run(n, 1, 0, 4),
            "per_image_pipelined_Msamples/s": run(n, 1, 2, 4 + n),
            "per_image_burst8_Msamples/s": run_bursts(4, 8, 4 + 2 * n),
-           "batch16_pipelined_Msamples/s": run(4, 16, 2, 36 + 2 * n),
+           "batch32_pipelined_Msamples/s": run(3, 32, 2, 36 + 2 * n),
            "callbacks": calls[0],
            "readback_bytes_per_image": W * H * 20,
            "note": "every variant includes the 20 B/pixel readback and the callback; per_image_* read back and show EVERY image "
                    "like the reference's loop: blocking = its launch / wait / read / callback sequence, pipelined = one launch per "
                    "image with two launches queued ahead, burst8 = the shim's default (8 images share a launch, "
-                   "ptmi_render_snapshots); batch16 = one callback per 16 images.  'value' above is 16 iterations per launch "
+                   "ptmi_render_snapshots); batch32 = one callback per 32 images.  'value' above is 32 iterations per launch "
                    "with one readback at the end"}
     res["per_image_vs_batched"] = res["per_image_burst8_Msamples/s"] / batched_value
     be.release()

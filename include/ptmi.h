@@ -136,7 +136,7 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* scene);
  * renders iterations [first_iteration, first_iteration + n_iterations) for
  * every pixel and adds them into the accumulators in iteration order (the
  * float sums equal a launch-per-iteration loop's bit for bit).  Internally
- * at most 16 iterations per kernel launch (1 with super_sampling, whose stop
+ * at most 32 iterations per kernel launch (1 with super_sampling, whose stop
  * criterion reads the accumulators of the previous iteration).  Asynchronous
  * on the context's stream. */
 int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations);

@@ -162,7 +162,10 @@ int launch_sum_images(float* out, const float* const* parts, uint32_t n_parts, s
 
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
 #ifndef PTMI_MAX_ITERATIONS_PER_LAUNCH
-#define PTMI_MAX_ITERATIONS_PER_LAUNCH 16
+// Measured on MI355X, 1M triangles 1080p (Msamples/s at 1 / 2 / 4 / 8 / 16 / 32 / 64 iterations per launch):
+// 614 / 668 / 697 / 722 / 763 / 778 / 782 - a persistent launch ramps up and ends ragged; 32 keeps the staging arrays at
+// 2 x 1.3 GB for a 1080p image (the cap falls with the image size, ptmi_setup_context)
+#define PTMI_MAX_ITERATIONS_PER_LAUNCH 32
 #endif
 constexpr uint32_t kMaxIterationsPerLaunch = PTMI_MAX_ITERATIONS_PER_LAUNCH;
 

@@ -167,7 +167,7 @@ def test_multi_device_bit_exact_parts_vs_oracle(scene_factory):
 @pytest.mark.gpu
 @pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
 def test_render_snapshots_leaves_every_image_of_the_per_image_loop(devices, scene_factory):
-    """ptmi_render_snapshots(first, n): iterations share launches (20 > 16 per launch: two chunks), yet slot k holds exactly
+    """ptmi_render_snapshots(first, n): iterations share one launch, yet slot k holds exactly
     what the reference's loop would have read back after image first + k."""
     w, h, d = 96, 64, 6
     sc = scene_factory("tris20k", w, h)

@@ -330,7 +330,7 @@ def test_wide_record_addresses(scene_factory, monkeypatch):
 
 
 def test_many_iterations_in_one_call_are_chunked(scene_factory):
-    """ptmi_render splits a long range into launches of <= 16 iterations (staging array bound): same bits."""
+    """ptmi_render splits a long range into launches of <= 32 iterations (staging array bound): same bits."""
     sc = scene_factory("cornell", 64, 48)
     color, count, (dep, _, _), counters = render_scene(sc, 64, 48, 4, 37)
     o_color, o_count, (o_dep, _, _), totals = O.oracle_render(sc, 64, 48, 4, 37)
