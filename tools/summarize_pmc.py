@@ -17,6 +17,6 @@ for name, per_dispatch in acc.items():
 extra = sys.argv[2] if len(sys.argv) > 2 else ""
 out["_spp_per_launch"] = 32  # bench.py's default --spp-per-step = one launch of 32 iterations per step
 out["_note"] = ("rocprofv3 --pmc <one group per run> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline --no-boundary " + extra + " (16 spp per launch, 1080p); per-launch means of "
+                "--no-cpu-baseline --no-boundary " + extra + " (32 spp per launch, 1080p); per-launch means of "
                 "render_wavefront_kernel; FETCH_SIZE/WRITE_SIZE in KB; GRBM_GUI_ACTIVE summed over the 8 XCDs")
 print(json.dumps(out, indent=1))
