@@ -297,8 +297,9 @@ def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
     """The integrator driven the way the reference drives its backend (OpenCL.cpp:76-107): ONE image per launch, the
     framebuffer read back into the viewer's buffers and a callback after EVERY image - through the same C ABI calls
     csrc/PathTracer_HIP.cpp makes.  Three variants: the reference's blocking sequence (launch, wait, read, callback),
-    the shim's default (launches of the next two images queued while image k crosses the bus: ptmi_snapshot /
-    ptmi_read_snapshot into page-locked buffers), and 32 images per launch and callback (PTMI_IMAGES_PER_LAUNCH=32)."""
+    one launch per image with the next two queued while image k crosses the bus (ptmi_snapshot / ptmi_read_snapshot into
+    page-locked buffers), the shim's default (16 images share a launch and each still gets its snapshot, readback and
+    callback: ptmi_render_snapshots), and 32 images per launch and callback (PTMI_IMAGES_PER_LAUNCH=32)."""
     import numpy as np
     be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=device, flags=flags)
     be.initialize_memory(scene)
@@ -348,16 +349,16 @@ def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
     res = {"images": n,
            "per_image_blocking_Msamples/s": run(n, 1, 0, 4),
            "per_image_pipelined_Msamples/s": run(n, 1, 2, 4 + n),
-           "per_image_burst8_Msamples/s": run_bursts(4, 8, 4 + 2 * n),
-           "batch32_pipelined_Msamples/s": run(3, 32, 2, 36 + 2 * n),
+           "per_image_burst16_Msamples/s": run_bursts(3, 16, 4 + 2 * n),
+           "batch32_pipelined_Msamples/s": run(3, 32, 2, 52 + 2 * n),
            "callbacks": calls[0],
            "readback_bytes_per_image": W * H * 20,
            "note": "every variant includes the 20 B/pixel readback and the callback; per_image_* read back and show EVERY image "
                    "like the reference's loop: blocking = its launch / wait / read / callback sequence, pipelined = one launch per "
-                   "image with two launches queued ahead, burst8 = the shim's default (8 images share a launch, "
+                   "image with two launches queued ahead, burst16 = the shim's default (16 images share a launch, "
                    "ptmi_render_snapshots); batch32 = one callback per 32 images.  'value' above is 32 iterations per launch "
                    "with one readback at the end"}
-    res["per_image_vs_batched"] = res["per_image_burst8_Msamples/s"] / batched_value
+    res["per_image_vs_batched"] = res["per_image_burst16_Msamples/s"] / batched_value
     be.release()
     return res
 

@@ -37,8 +37,8 @@
 //
 // Environment knobs (all optional):
 //   PTMI_DEVICES = "all" (default) or a comma-separated list of HIP ordinals;  PTMI_DEVICE = one ordinal (wins)
-//   PTMI_BURST = images that share one kernel launch while EACH still gets its readback and callback, in order (default 8:
-//                the viewer sees every image of the reference's loop, in bursts, at the throughput of 8 images per launch;
+//   PTMI_BURST = images that share one kernel launch while EACH still gets its readback and callback, in order (default 16:
+//                the viewer sees every image of the reference's loop, in bursts, at the throughput of 16 images per launch;
 //                1 = one launch per image)
 //   PTMI_IMAGES_PER_LAUNCH = images rendered per step AND per callback (default 1 = the reference's count of callbacks)
 //   PTMI_LOOKAHEAD = steps queued ahead of the one being read back when PTMI_BURST is 1 (default max(2, devices); 0 = the
@@ -194,7 +194,7 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
                          last_image, numImagesToRender, g_devices, t_path, t_mem, t_disp);
     };
     // ---- bursts: B images per launch, a snapshot behind every one of them (ptmi_render_snapshots), one burst queued ahead
-    unsigned burst = env_uint("PTMI_BURST", 8);
+    unsigned burst = env_uint("PTMI_BURST", 16);
     const unsigned ring = PTMI_MAX_SNAPSHOT_SLOTS - 1;
     if (burst > ring / 2) burst = ring / 2;
     if (batch == 1 && burst > 1 && sampler_owns_pixels(globalVars)) {
