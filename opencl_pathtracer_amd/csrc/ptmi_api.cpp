@@ -261,7 +261,7 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
     out.tris_precomputed = std::getenv("PTMI_GENERIC_TRIANGLES") == nullptr;  // developer switch for A/B runs
     for (uint32_t i = 0; i < nt && out.tris_precomputed; i++) {
         const ptmi_triangle& t = sc->triangulation[i];
-        if (!(t.s1.w == t.s2.w && t.s1.w == t.s3.w)) out.tris_precomputed = false;
+        if (!(t.s1.w == t.s2.w && t.s1.w == t.s3.w && std::isfinite(t.s1.w))) out.tris_precomputed = false;  // edge vectors need w = +0 exactly
     }
     if (out.tris_precomputed) {
         auto dot4 = [](const float a[4], const float b[4]) {

@@ -280,6 +280,10 @@ __device__ __forceinline__ float div_unscaled(float a, float b)
 // The rejections are the reference's (FullKernel.cl:519-589) with unchanged operands; only their order differs -
 // the behind-the-ray test (:566) moves up next to the distance tests - which cannot change the outcome because the
 // function has no side effects before it accepts.
+// (Tried in round 2 and dropped, both slower although they issue fewer arithmetic instructions - the compiler's pairing
+// of the dot products into packed fma breaks and moves / spills come back: 3-component dot products for the five
+// barycentric dots of a precomputed record, whose edge vectors have w = +0 (778 -> 772 Msamples/s); a second copy of the
+// traversal loop for waves whose rays all have direction.w = 0, which drops six more instructions per test (778 -> 763).)
 template <bool PRE, class LateQuads, class OnAccept>
 __device__ __forceinline__ void tri_test(const float4 e0, const float4 e1, LateQuads&& late_quads, const Ray& r,
                                          const float limit, OnAccept&& on_accept)
