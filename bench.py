@@ -143,6 +143,7 @@ def main():
     for s in range(args.warmup, args.warmup + args.steps):
         step(s)
     if args.backend == "gloo" and world > 1:  # rehearsal path: gloo has no device tensors
+        be.synchronize()  # the launches run on the integrator's own streams
         host = fb.buffer.cpu()
         dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
         fb.buffer.copy_(host)
