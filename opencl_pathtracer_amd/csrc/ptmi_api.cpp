@@ -692,26 +692,31 @@ int gather_snapshot(ptmi_ctx* ctx, uint32_t slot, const float** image)
     }
     const float* parts[PTMI_MAX_DEVICES];
     parts[0] = lead.d_snapshot[slot];
+    // the previous sum must have read the landing buffers before they are overwritten: the peers' copies wait for the lead's
+    // copy stream as it stands now
+    hipEvent_t& gate = lead.peer_copied;
+    if (!gate) HIP_TRY(ctx, hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(gate, lead.copy_stream));
     for (uint32_t k = 1; k < ctx->n_dev(); k++) {
         DeviceState& d = ctx->dev[k];
-        if (!d.d_peer_copy) {
+        if (!d.d_peer_copy) {  // on devices[0] (the lead device is current)
             void* p = nullptr;
-            HIP_TRY(ctx, hipMalloc(&p, npix * 20));  // on devices[0]: the lead device is current
+            HIP_TRY(ctx, hipMalloc(&p, npix * 20));
             d.d_peer_copy = (float*)p;
-            HIP_TRY(ctx, hipEventCreateWithFlags(&d.peer_copied, hipEventDisableTiming));
         }
-        // the previous sum must have read this buffer before it is overwritten: copy_stream order covers it, because the
-        // copy below waits for the lead's copy stream through an event recorded there
-        hipEvent_t& gate = lead.peer_copied;
-        if (!gate) HIP_TRY(ctx, hipEventCreateWithFlags(&gate, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventRecord(gate, lead.copy_stream));
+        parts[k] = d.d_peer_copy;
+    }
+    for (uint32_t k = 1; k < ctx->n_dev(); k++) {  // each peer pushes its snapshot over its own link, on a stream and with an event of its own device
+        DeviceState& d = ctx->dev[k];
+        ON_DEVICE(ctx, d);
+        if (!d.peer_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&d.peer_copied, hipEventDisableTiming));
         HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, gate, 0));
         HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, d.snapshot_ready[slot], 0));
         HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_peer_copy, lead.device, d.d_snapshot[slot], d.device, npix * 20, d.copy_stream));
         HIP_TRY(ctx, hipEventRecord(d.peer_copied, d.copy_stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, d.peer_copied, 0));
-        parts[k] = d.d_peer_copy;
     }
+    ON_DEVICE(ctx, lead);
+    for (uint32_t k = 1; k < ctx->n_dev(); k++) HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, ctx->dev[k].peer_copied, 0));
     if (!ctx->d_reduced) {
         void* p = nullptr;
         HIP_TRY(ctx, hipMalloc(&p, npix * 20));
