@@ -25,7 +25,7 @@ import numpy as np
 
 from . import structs as S
 
-# PTMI_LIBRARY lets a developer A/B another in-tree build of the same ABI (tools/sweep_variants.sh)
+# PTMI_LIBRARY lets a developer A/B another in-tree build of the same ABI (tools/build_variants.sh, tools/run_variants.sh)
 _LIB_PATH = os.environ.get("PTMI_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libptmi.so")
 _lib = None
 
