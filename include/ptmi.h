@@ -215,9 +215,10 @@ int ptmi_set_stream(ptmi_ctx* ctx, void* hip_stream);
 int ptmi_device_accumulators(ptmi_ctx* ctx, void** d_image_color, void** d_image_ray_nb);
 
 /* SUPER_SAMPLING only: the per-pixel variance accumulator global__imageV (float4[W*H]; the sum of squared
- * deviations the stop criterion reads, FullKernel.cl:1152-1172,1346-1349).  Needed to combine the shards of a multi-GPU
- * render, where it does not merge by a plain sum (opencl_pathtracer_amd/distributed.py: merge_moments).
- * PTMI_ERR_STATE without super_sampling. */
+ * deviations the stop criterion reads, FullKernel.cl:1152-1172,1346-1349).  On a multi-device context every device
+ * samples adaptively on its own accumulators (its stop decisions are its own) and ptmi_read_variance returns the moments
+ * of all devices merged pairwise (Chan's update; the same arithmetic as opencl_pathtracer_amd/distributed.py:
+ * merge_moments, which does it across processes).  PTMI_ERR_STATE without super_sampling. */
 int ptmi_read_variance(ptmi_ctx* ctx, float* image_v);
 int ptmi_write_variance(ptmi_ctx* ctx, const float* image_v); /* with ptmi_write_image: resume a SUPER_SAMPLING render */
 int ptmi_device_variance(ptmi_ctx* ctx, void** d_image_v);

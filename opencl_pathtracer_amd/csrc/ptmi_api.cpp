@@ -777,10 +777,6 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
     if (cfg->super_sampling && (cfg->sampler == PTMI_SAMPLER_RANDOM || (cfg->flags & PTMI_FLAG_MEGAKERNEL)))
         return fail(nullptr, PTMI_ERR_UNSUPPORTED,
                     "SUPER_SAMPLING needs a sampler that owns its pixel (JITTERED/UNIFORM) and the wavefront kernel");
-    if (cfg->super_sampling && cfg->n_devices > 1)
-        return fail(nullptr, PTMI_ERR_UNSUPPORTED,
-                    "SUPER_SAMPLING on several devices: the variance image does not merge by a sum (one context per device and "
-                    "distributed.reduce_super_sampling instead)");
 
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -1146,6 +1142,7 @@ int ptmi_device_variance(ptmi_ctx* ctx, void** d_image_v)
 {
     if (!ctx || !d_image_v) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_device_variance before ptmi_initialize_memory");
+    if (ctx->n_dev() != 1) return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_device_variance on a multi-device context (per-device moments)");
     if (!ctx->dev[0].ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
     *d_image_v = ctx->dev[0].ds.image_v;
     return PTMI_OK;
@@ -1155,11 +1152,39 @@ int ptmi_read_variance(ptmi_ctx* ctx, float* image_v)
 {
     if (!ctx || !image_v) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_variance before ptmi_initialize_memory");
-    DeviceState& d = ctx->dev[0];
-    if (!d.ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
-    ON_DEVICE(ctx, d);
-    HIP_TRY(ctx, hipMemcpyAsync(image_v, d.ds.image_v, ctx->npix() * 16, hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    DeviceState& d0 = ctx->dev[0];
+    if (!d0.ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
+    const size_t npix = ctx->npix();
+    ON_DEVICE(ctx, d0);
+    HIP_TRY(ctx, hipMemcpyAsync(image_v, d0.ds.image_v, npix * 16, hipMemcpyDeviceToHost, d0.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(d0.stream));
+    if (ctx->n_dev() == 1) return PTMI_OK;
+    // Several devices: each kept (sum S, count n, imageV = sum of squared deviations M2) of ITS samples.  S and n add; M2
+    // does not:  M2 = M2_a + M2_b + (mean_b - mean_a)^2 * n_a * n_b / (n_a + n_b)   (Chan, Golub, LeVeque).  Merged here on
+    // the host, device after device, in fp32 with the operation order of distributed.merge_moments.
+    std::vector<float> sum(npix * 4), cnt(npix), sb(npix * 4), nb(npix), vb(npix * 4);
+    HIP_TRY(ctx, hipMemcpy(sum.data(), d0.ds.image_color, npix * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(cnt.data(), d0.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToHost));
+    for (uint32_t k = 1; k < ctx->n_dev(); k++) {
+        DeviceState& d = ctx->dev[k];
+        ON_DEVICE(ctx, d);
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+        HIP_TRY(ctx, hipMemcpy(sb.data(), d.ds.image_color, npix * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(nb.data(), d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(vb.data(), d.ds.image_v, npix * 16, hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < npix; p++) {
+            const float na = cnt[p], nbp = nb[p], n = na + nbp;
+            const float sa_ = na > 0 ? na : 1.f, sb_ = nbp > 0 ? nbp : 1.f, sn_ = n > 0 ? n : 1.f;
+            const bool both = na > 0 && nbp > 0;
+            for (int c = 0; c < 4; c++) {
+                const float delta = sb[4 * p + c] / sb_ - sum[4 * p + c] / sa_;
+                const float cross = delta * delta * (na * nbp / sn_);
+                image_v[4 * p + c] = (image_v[4 * p + c] + vb[4 * p + c]) + (both ? cross : 0.f);
+                sum[4 * p + c] = sum[4 * p + c] + sb[4 * p + c];
+            }
+            cnt[p] = n;
+        }
+    }
     return PTMI_OK;
 }
 
@@ -1167,6 +1192,7 @@ int ptmi_write_variance(ptmi_ctx* ctx, const float* image_v)
 {
     if (!ctx || !image_v) return PTMI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_write_variance before ptmi_initialize_memory");
+    if (ctx->n_dev() != 1) return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_write_variance on a multi-device context");
     DeviceState& d = ctx->dev[0];
     if (!d.ds.image_v) return fail(ctx, PTMI_ERR_STATE, "no variance accumulator: the context was set up without super_sampling");
     ON_DEVICE(ctx, d);

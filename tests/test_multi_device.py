@@ -96,10 +96,38 @@ def test_one_image_per_call_over_two_devices(scene_factory):
 
 
 @pytest.mark.gpu
-def test_super_sampling_needs_one_device(built):
-    with pytest.raises(PtmiError) as e:
-        Backend().setup_context(8, 8, 2, 0, super_sampling=True, devices=[0, 0])
-    assert e.value.code == -7
+def test_super_sampling_on_two_devices_merges_the_moments(scene_factory):
+    """SUPER_SAMPLING with the ids dealt to two devices: each samples adaptively on its own accumulators; the image is the
+    sum, the variance image the pairwise merge of the two devices' moments - equal to merging, with
+    distributed.merge_moments, two single-device contexts that rendered the same ids."""
+    import torch
+    from opencl_pathtracer_amd.distributed import merge_moments
+    w, h, d, n = 64, 48, 4, 18
+    sc = scene_factory("cornell", w, h)
+    multi = Backend().setup_context(w, h, d, sc.lightsSize, super_sampling=True, devices=[0, 0])
+    multi.initialize_memory(sc)
+    multi.render(0, n)
+    mc, mn = multi.read_image()
+    mv = multi.read_variance()
+    with pytest.raises(PtmiError):
+        multi.device_variance()
+    multi.release()
+    parts = []
+    for k in range(2):
+        be = Backend().setup_context(w, h, d, sc.lightsSize, super_sampling=True)
+        be.initialize_memory(sc)
+        for it in range(k, n, 2):
+            be.render(it, 1)
+        c, cn = be.read_image()
+        parts.append((c, cn, be.read_variance()))
+        be.release()
+    (ca, na, va), (cb, nb, vb) = parts
+    assert np.array_equal(mn, na + nb) and mn.min() < n  # adaptive: some pixels were skipped
+    assert np.array_equal(mc.view(np.uint32), (ca + cb).view(np.uint32))
+    t = lambda a, shape: torch.from_numpy(np.ascontiguousarray(a).reshape(shape))
+    _, _, m2 = merge_moments(t(ca, (-1, 4)), t(na, (-1,)), t(va, (-1, 4)), t(cb, (-1, 4)), t(nb, (-1,)), t(vb, (-1, 4)))
+    assert np.isfinite(mv).all()
+    assert np.allclose(mv.reshape(-1, 4), m2.numpy(), rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.gpu
