@@ -2,10 +2,11 @@
 
 tests/golden/ref_<case>.npz were produced on an MI355X by tests/golden/make_reference_fixtures.py from
 oracle/_ref/ref_kernel_<case>.hsaco = the reference's Kernel/PathTracer_FullKernel.cl compiled unmodified for
-gfx950 (OpenCL default arithmetic).  The oracle evaluates the same algorithm under the strict numerics
-contract of DESIGN.md, so the comparison is statistical (see test_parity_gpu.test_vs_reference_kernel_on_gpu
-for why bit-equality with any build of the reference is impossible), calibrated on the fixture's own
-`noise_floor_rms_16spp` = distance between two legal builds of the reference:
+gfx950, in two builds.  Against the STRICT build (IEEE operations in the written order + the platform library's dot /
+normalize / sin / cos, which is the oracle's own arithmetic) the comparison is bit for bit
+(test_oracle_equals_the_reference_strict_build*).  Against the DEFAULT build (FMA contraction, approximate divide and
+sqrt: other legal arithmetic) it is statistical, calibrated on the fixture's own `noise_floor_rms_16spp` = the distance
+between the reference's two builds:
   * sample counts exact; depth histograms within 1e-3 of the paths; traversal-work histograms close;
   * per sample (1 spp): <= 1 % flipped, median relative difference <= 1e-6, no bias;
   * 16-spp image: RMS <= max(2e-4, 3 x noise floor), or else <= 0.5 % of the pixels hold a sample that took

@@ -431,11 +431,10 @@ def test_bad_scene_is_an_error_not_a_fault(scene_factory):
 def test_vs_reference_kernel_on_gpu(case, scene_factory):
     """The reference's own Kernel_Main (unmodified source -> gfx950 code object) on the same inputs.
 
-    OpenCL leaves dot/normalize/sin/cos, FMA contraction and divide/sqrt accuracy to the implementation (AMD's
-    normalize() is p * v_rsq_f32(dot), a hardware approximation), and the integrator is chaotic at a few
-    decisions (shadow rays without epsilon at grazing incidence, hits on edges): no other implementation can
-    match one build of the reference bit for bit.  So the check is statistical, calibrated on the reference's
-    distance to ITSELF (its strict-IEEE build vs its default build):
+    This is the reference's DEFAULT build: FMA contraction and approximate divide / sqrt, i.e. other legal arithmetic
+    than the strict build the integrator equals bit for bit (tests/test_reference_strict_gpu.py), and the integrator
+    is chaotic at a few decisions (shadow rays without epsilon at grazing incidence, hits on edges).  So this check is
+    statistical, calibrated on the reference's distance to ITSELF (its strict build vs its default build):
       * path statistics: depth histogram within 1e-3 of the paths;
       * per sample (1 spp): <= 1 % of the samples take another branch, the rest agree to rounding, no bias;
       * image at 64 spp: RMS <= max(1e-4, 3 x RMS(reference default vs reference strict))."""
