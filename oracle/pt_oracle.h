@@ -18,11 +18,17 @@
  *     tests/golden/ with the script that made them.
  *   - BVH_Create compiled UNMODIFIED for x86-64 (target `ref-bvh` ->
  *     oracle/_ref/libref_bvh.so) pins the product's BVH builder.
- * Arithmetic choices that OpenCL leaves implementation-defined (association
- * order of dot(), normalize() as a true division, sin/cos) are fixed once, in
- * vec helpers below and in include/ptmi_detmath.h; the reference-on-gfx950
- * differs from them in the last bits (FMA contraction, rsqrt), which is why
- * that comparison is an RMS tolerance and HIP-vs-oracle is (near) bit-exact.
+ * Arithmetic that OpenCL leaves implementation-defined follows the platform
+ * the reference runs on here (ROCm OpenCL device library on gfx950): dot()
+ * and cross() as its fma chains, normalize() = v * rsqrt(dot) with its range
+ * scaling and the hardware's v_rsq_f32 (deviation table measured on the
+ * MI355X, tests/golden/rsq_gfx950.npz, see pto_set_rsq_table), sin/cos as its
+ * argument reduction + polynomials (include/ptmi_detmath.h); every other
+ * operation is one correctly rounded IEEE operation in the written order.
+ * That is the reference's STRICT build (-ffp-contract=off
+ * -cl-fp32-correctly-rounded-divide-sqrt), which the oracle equals bit for
+ * bit (tests/test_oracle_golden.py); its DEFAULT build is other legal
+ * arithmetic and is compared statistically.
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
