@@ -48,13 +48,14 @@ namespace ptmi_dev {
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #ifndef PTMI_WF_WAIT_DEBT
-// lane-trips of waiting a wave tolerates before it spends a pass on path logic.  Measured on MI355X, one box per
-// scene, final r01 kernel (Msamples/s: 1M triangles 1080p / Cornell box 1080p d8 / material mix 4K d16):
-//   256: - / 4883 / 1876    384: 733 / - / 1969    512: 740 / 4804 / 1986    768: 742 / 4896 / 1944
-//   1024: 737 / 4845 / 1872    2048: - / 4840 / 1718
-// (a fixed threshold of 8 waiting lanes instead of a debt measured 474 / 743 with an early build; sweeps made while
-// the job-queue counters still shared a cache line favoured 1024+ on the small scenes - that was the atomics)
-#define PTMI_WF_WAIT_DEBT 512
+// lane-trips of waiting a wave tolerates before it spends a pass on path logic: a launch parameter (DWarm::wait_debt),
+// 512 for shallow trees, 768 from depth 16 on; PTMI_WF_WAIT_DEBT > 0 fixes it at build time for sweeps.
+// Measured on MI355X (Msamples/s: 1M triangles 1080p depth 20 / Cornell box 1080p d8 depth 5 / material mix 4K d16):
+//   round 2, leaf passes:   512: 885 / 5388 / 2344    768: 895 / 5172 / 2314    1024: 895 / 5121 / 2235
+//   round 1, mixed trips:   256: - / 4883 / 1876    384: 733 / - / 1969    512: 740 / 4804 / 1986    768: 742 / 4896 / 1944
+//                           1024: 737 / 4845 / 1872    2048: - / 4840 / 1718
+// (a fixed threshold of 8 waiting lanes instead of a debt measured 474 / 743 with an early build)
+#define PTMI_WF_WAIT_DEBT 0
 #endif
 #ifndef PTMI_WF_MIN_WAVES
 // waves per SIMD the register allocator must fit (5 -> 96 VGPRs, the overflow spills to scratch inside the path-logic
@@ -70,7 +71,7 @@ constexpr int kQueues = PTMI_WF_QUEUES;  // job queues (image stripes), one per 
 #define PTMI_WF_QUEUE_STRIDE 64
 #endif
 constexpr int kQueueStride = PTMI_WF_QUEUE_STRIDE;  // dwords between two queue counters (64 = one 256-byte block each)
-constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
+constexpr int kWaitDebtFixed = PTMI_WF_WAIT_DEBT;
 #ifndef PTMI_WF_HIT_WORDS
 // LDS words of the closest-hit record per lane.  8: hit point (4), s, t, triangle | front, found.  4: the ray parameter
 // instead of the point - path logic rebuilds the point from the ray it still holds with the very operations of the
@@ -81,6 +82,26 @@ constexpr int kWaitDebt = PTMI_WF_WAIT_DEBT;
 #endif
 constexpr int kHitWords = PTMI_WF_HIT_WORDS;
 static_assert(kHitWords == 4 || kHitWords == 8, "closest-hit record: 4 or 8 words");
+#ifndef PTMI_WF_LEAF_PASS
+// 1: LEAF PASSES.  A lane that reaches a leaf does not test its triangles itself, one per trip, under whatever exec mask the
+// trip happens to have; it waits, and when enough lanes wait the wave runs one pass in which the triangles of ALL waiting
+// leaves are dealt out as work items, one per lane, to all 64 lanes (the ray of an item's owner travels through the
+// cross-lane network).  A leaf of 3 triangles costs one pass at full lane utilisation instead of three trips at ~30 %.
+// Same tests, same order of acceptance per ray (see leaf_pass): results bit-identical.
+#define PTMI_WF_LEAF_PASS 1
+#endif
+constexpr bool kLeafPass = PTMI_WF_LEAF_PASS != 0;
+static_assert(!kLeafPass || kHitWords == 4, "leaf passes write the 4-word closest-hit record");
+#ifndef PTMI_WF_LEAF_LANES
+#define PTMI_WF_LEAF_LANES 19
+#endif
+#ifndef PTMI_WF_LEAF_RATIO
+#define PTMI_WF_LEAF_RATIO 2
+#endif
+// a pass (up to 64 triangles, one per lane) runs when this many lanes wait at a leaf (3 triangles each on average), or when
+// the waiting triangles are kLeafRatio times as many as the lanes left to take node steps
+constexpr int kLeafLanes = PTMI_WF_LEAF_LANES, kLeafRatio = PTMI_WF_LEAF_RATIO;
+constexpr int kLeafPassWords = kLeafPass ? 4 * kWfBlock : 0;  // LDS: one 64-bit key per lane + 64 items of 8 bytes per wave
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
 // rest of DScene (sky: only when a path escapes; histogram / RANDOM-sampler / SUPER_SAMPLING buffers; counters)
@@ -104,6 +125,7 @@ struct DWarm {
     uint32_t boxes_ordered;
     uint32_t wide_records;  // the record array is 4 GB or more: 64-bit addressing
     uint32_t russian_roulette;  // PTMI_FLAG_RUSSIAN_ROULETTE (non-parity mode)
+    uint32_t wait_debt;         // see PTMI_WF_WAIT_DEBT
 };
 
 // A finished path's three histogram bins in one word: depth (6 bits, < kStatDepthBins), box tests and triangle tests
@@ -283,6 +305,143 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         }
     };
 
+    // ---- leaf passes (kLeafPass) -----------------------------------------------------------------------------------
+    // Per wave: items = the next (up to 4) triangles of every lane that waits at a leaf, numbered owner by owner (prefix sum
+    // of the counts from three ballots); a pass takes the first 64 and lane k tests item k with the OWNER's ray, limit and
+    // mode (an owner whose triangles did not all fit offers the rest to the next pass).
+    // Equivalence with the reference's leaf loop (FullKernel.cl:638-646, limit updated between tests):
+    //   closest hit: a triangle is accepted iff it passes every other test and its squared distance <= the current limit,
+    //     which then becomes that distance; so after the leaf the record holds the LAST triangle (in index order) among
+    //     those that pass against the limit at entry with the smallest distance: one 64-bit minimum per owner over the key
+    //     (distance bits, ~index).  Testing against the limit at entry only admits candidates that lose that minimum.
+    //   shadow: the FIRST triangle that passes ends the query (:724-727) and only the tests up to it are counted:
+    //     a minimum over the index.
+    // All LDS traffic of a pass stays inside the wave (LDS operations of one wave execute in order): no barrier.
+    unsigned long long* const key_mem = reinterpret_cast<unsigned long long*>(&stack_mem[(kHitWords + 1 + stack_levels) * kWfBlock]);
+    uint2* const item_mem = reinterpret_cast<uint2*>(&stack_mem[(kHitWords + 3 + stack_levels) * kWfBlock]) + (tid & ~63u);
+    const uint32_t lane = tid & 63u, wave_first = tid & ~63u;
+    uint32_t pass_rounds = 0, pass_items = 0;
+    auto leaf_pass = [&](bool waits_at_leaf) {
+        auto lanes_below = [&](unsigned long long m) {
+            return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        };
+        // triangles this lane offers (up to 4 of its leaf's), as three bit planes over the wave: prefix sum and total
+        const uint32_t left = tri_end - tri_i;
+        const uint32_t offered = waits_at_leaf ? (left < 4u ? left : 4u) : 0u;
+        const unsigned long long plane0 = __builtin_amdgcn_ballot_w64((offered & 1u) != 0), plane1 = __builtin_amdgcn_ballot_w64((offered & 2u) != 0),
+                                 plane2 = __builtin_amdgcn_ballot_w64((offered & 4u) != 0);
+        const int n_items = __popcll(plane0) + 2 * __popcll(plane1) + 4 * __popcll(plane2);
+        // one pass = one item per lane: the first 64 items; an owner whose triangles do not all fit keeps the rest
+        const uint32_t first_item = lanes_below(plane0) + 2u * lanes_below(plane1) + 4u * lanes_below(plane2);
+        const uint32_t room = first_item < 64u ? 64u - first_item : 0u;
+        const uint32_t cnt = offered < room ? offered : room;
+        const uint32_t n_now = n_items < 64 ? (uint32_t)n_items : 64u;  // wave-uniform
+        if (STATS) { pass_rounds++; pass_items += n_now; }
+        if (cnt != 0u) {
+            key_mem[tid] = shadow ? ~0ull : (((unsigned long long)__float_as_uint(limit) << 32) | 0xFFFFFFFFull);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)  // item = (triangle record index (< 2^27) | shadow query, owner)
+                if (j < cnt) item_mem[first_item + j] = make_uint2((tri_i + j) | (shadow ? 0x80000000u : 0u), lane);
+        }
+        {
+            const bool has_item = lane < n_now;
+            // one LDS read tells a lane its triangle and its owner: the record loads go out before the owner's ray is fetched
+            // (items of one byte - owner and position - with the triangle index fetched from the owner: 864 -> 896 Msamples/s)
+            const uint2 item = has_item ? item_mem[lane] : make_uint2(0u, 0u);
+            const uint32_t owner = item.y;
+            const int from = (int)(owner << 2);
+            auto fetch = [&](float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(x))); };
+            const uint32_t w_tri = item.x & 0x7FFFFFFFu;
+            const bool w_shadow = (item.x >> 31) != 0u;
+            const float4* const rec = reinterpret_cast<const float4*>(&sc.tris[has_item ? w_tri : 0u]);
+            constexpr int kE1 = PRE ? 1 : 3, kL0 = PRE ? 2 : 1, kL1 = PRE ? 3 : 2;
+            const float4 e0 = rec[0], e1 = rec[kE1];  // (lanes without an item read record 0: in bounds, unused)
+            asm volatile("" ::: "memory");  // (keeps the loads above the ray fetches: 860 -> 894 Msamples/s)
+            Ray wr;
+            wr.o = v4(fetch(r.o.x), fetch(r.o.y), fetch(r.o.z), fetch(r.o.w));
+            wr.d = v4(fetch(r.d.x), fetch(r.d.y), fetch(r.d.z), fetch(r.d.w));
+            wr.ix = wr.iy = wr.iz = 0;
+            const float w_limit = fetch(limit);
+            if (has_item) {
+                unsigned long long* const owner_key = &key_mem[wave_first + owner];
+                // (all four quads up front instead of two now and two for the lanes that pass the distance tests: +0.3 %, not kept)
+                tri_test<PRE>(e0, e1, [&](float4& l0, float4& l1) { l0 = rec[kL0]; l1 = rec[kL1]; }, wr, w_limit,
+                              [&](const V4&, float ray_t, float s, float t, bool front, float nsd) {
+                    // every lane that accepts is here at the same time: one LDS minimum for all of them, then each asks
+                    // whether it is (so far) the one its owner keeps
+                    const unsigned long long key = w_shadow ? ((unsigned long long)w_tri << 32)
+                                                            : (((unsigned long long)__float_as_uint(nsd) << 32) | (unsigned long long)(~w_tri));
+                    atomicMin(owner_key, key);
+                    if (!w_shadow && *owner_key == key) {  // the closest so far: its record is the one path logic shades from
+                        uint32_t* const rec_out = &stack_mem[wave_first + owner];
+                        rec_out[0 * kWfBlock] = __float_as_uint(ray_t);
+                        rec_out[kWordS * kWfBlock] = __float_as_uint(s);
+                        rec_out[kWordT * kWfBlock] = __float_as_uint(t);
+                        rec_out[kWordTri * kWfBlock] = w_tri | (front ? kHitFront : 0u) | kHitFound;
+                    }
+                });
+            }
+        }
+        if (cnt != 0u) {
+            const uint32_t won = (uint32_t)(key_mem[tid] >> 32);
+            if (!shadow) {
+                limit = __uint_as_float(won);
+                p_tri += cnt; tri_i += cnt;
+            } else if (won != 0xFFFFFFFFu) {
+                p_tri += won - tri_i + 1u;
+                hit_mem[kWordTri * kWfBlock] |= kHitFound;
+                tri_end = tri_i; cur = REF_NONE;
+            } else {
+                p_tri += cnt; tri_i += cnt;
+            }
+            if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {
+                decode_leaf(sc, cur, tri_i, tri_end);
+                cur = *sp;
+                uint32_t* const under = sp - kWfBlock;
+                sp = under < stack_floor ? stack_floor : under;
+            }
+        }
+    };
+    // one inner-node step of the calling lanes (:660-697): the same code as in the mixed trip below
+    // (always the 64-bit address form here: one instruction more than the 32-bit offset of the mixed trip, measured
+    // faster - 851 vs 837 Msamples/s - than choosing between the two)
+    auto node_step = [&]() {
+        const float4* const rec = reinterpret_cast<const float4*>(&sc.tris[cur & REF_INDEX_MASK_INNER]);
+        const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+        const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
+        const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
+        const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
+        const bool a0 = axis == 0, a1 = axis == 1;
+        const bool fwd = (a0 & (r.d.x > 0)) | (a1 & (r.d.y > 0)) | (!(a0 | a1) & (r.d.z > 0));
+        bool h1, h2;
+        if (!wave_exact) {
+            h1 = box_hit_ordered(lo1, hi1, r, limit);
+            h2 = box_hit_ordered(lo2, hi2, r, limit);
+        } else {
+            h1 = box_hit(lo1, hi1, (ref1 & REF_EMPTY) != 0, r, limit);
+            h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
+        }
+        p_bbx += 2;
+        const uint32_t far_ref = fwd ? ref2 : ref1;
+        const bool both = h1 & h2;
+        sp[kWfBlock] = far_ref;
+        sp += both ? kWfBlock : 0;
+        cur = fwd ? (h1 ? ref1 : ref2) : (h2 ? ref2 : ref1);
+        {
+            const bool need_pop = !(h1 | h2);
+            const uint32_t popped = *sp;
+            uint32_t* const under = sp - kWfBlock;
+            cur = need_pop ? popped : cur;
+            sp = need_pop ? (under < stack_floor ? stack_floor : under) : sp;
+        }
+        if (cur != REF_NONE && (cur & REF_LEAF)) {  // (the triangle range of a lane that takes node steps is free)
+            decode_leaf(sc, cur, tri_i, tri_end);
+            cur = *sp;
+            uint32_t* const under = sp - kWfBlock;
+            sp = under < stack_floor ? stack_floor : under;
+        }
+    };
+
     // Scheduling of path logic: a fixed lane threshold cannot serve both a 21-node scene (queries of ~10 steps,
     // all lanes finish together: waiting for a full wave is nearly free and a threshold of 8 runs the long
     // path-logic code at 12 % utilisation: 743 vs 2897 Msamples/s on the Cornell box) and a million-triangle
@@ -308,6 +467,12 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         n_t = __popcll(m_t); n_i = __popcll(m_i); n_p = __popcll(m_p);
         wait_debt += n_p;
     };
+    // path logic is due / nothing can traverse (then every waiting lane is served)
+    // (Tried: a wait debt of its own for the lanes whose shadow query has finished - the expensive kind of path logic - so
+    // that each kind is served at a higher lane count: 809 -> 685-700 Msamples/s; lanes kept waiting are lanes that do not traverse.)
+    const int wait_debt_bound = kWaitDebtFixed > 0 ? kWaitDebtFixed : (int)sc.wait_debt;
+    auto path_logic_due = [&]() { return n_p > 0 && wait_debt >= wait_debt_bound; };
+    auto nothing_traverses = [&]() { return n_t == 0 && n_i == 0; };
     // Loop nest: path logic in the outer loop, traversal trips in an inner loop of their own, so that the traversal
     // state is loop-carried through ONE small loop (as one if/else in one loop the two big branches were merged through
     // temporaries: 16 v_mov per trip).  Progress: a trip or a path-logic pass only runs with at least one lane wanting
@@ -315,7 +480,29 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     for (;;) {
         survey();
         if (!any_lane) break;
-        if (!((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0))) {
+        if (kLeafPass) {
+            // node trips for the lanes at inner nodes; a leaf pass when enough lanes wait at leaves (or as many as run)
+            // (node trips in a loop of their own: their state is carried through one small loop without copies)
+            auto to_path_logic = [&]() { return path_logic_due() || nothing_traverses(); };
+            auto pass_is_due = [&]() { return n_t >= kLeafLanes || (n_t > 0 && 3 * n_t >= kLeafRatio * n_i); };
+            // (One loop for both kinds of trip.  Tried: node trips in an inner loop of their own - same schedule, 851 -> 807
+            // Msamples/s; the node step of the lanes at inner nodes in the same trip as a pass, its record loads in flight
+            // during the pass - 894 -> 791, the sixteen registers held across the pass spill; requesting the record of a lane's
+            // next node as soon as the step has chosen it, before the wave has counted its lanes and decided what the next trip
+            // is - 895 -> 724: the requests of lanes that turn out to wait are extra L1 traffic, and the loop-carried
+            // registers cost sixteen copies per trip.)
+            while (!to_path_logic()) {
+                if (pass_is_due()) {
+                    leaf_pass(pending);
+                    survey();
+                    continue;
+                }
+                if (STATS) { trips_i++; lanes_i += n_i; }
+                if (want_inner) node_step();
+                survey();
+            }
+        } else
+        if (!(path_logic_due() || nothing_traverses())) {
             for (;;) {
                 // ===================== traversal trip: EVERY traversing lane takes one step ====================
                 // A DNode and a DTri are both one aligned 64-byte record, so node lanes and triangle lanes issue
@@ -414,7 +601,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     }
                 }
                 survey();
-                if ((n_p > 0 && wait_debt >= kWaitDebt) || (n_t == 0 && n_i == 0)) break;
+                if (path_logic_due() || nothing_traverses()) break;
             }
         }
         wait_debt = 0;
@@ -588,8 +775,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     if (STATS && (tid & 63u) == 0) {  // one lane per wave: the scheduler counters are wave-uniform
         atomicAdd(&block_counters[C_TRIPS_I], (unsigned long long)trips_i);
         atomicAdd(&block_counters[C_LANES_I], lanes_i);
-        atomicAdd(&block_counters[C_TRIPS_T], (unsigned long long)trips_t);
-        atomicAdd(&block_counters[C_LANES_T], lanes_t);
+        atomicAdd(&block_counters[C_TRIPS_T], (unsigned long long)(kLeafPass ? pass_rounds : trips_t));
+        atomicAdd(&block_counters[C_LANES_T], kLeafPass ? (unsigned long long)pass_items : lanes_t);
         atomicAdd(&block_counters[C_TRIPS_P], (unsigned long long)trips_p);
         atomicAdd(&block_counters[C_LANES_P], lanes_p);
         atomicAdd(&block_counters[C_CYCLES_P], cycles_p);
@@ -698,7 +885,8 @@ static uint32_t clamp_levels(uint32_t stack_levels)
 static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
     stack_levels = clamp_levels(stack_levels);
-    return (size_t)(stack_levels + 1 + ptmi_dev::kHitWords) * ptmi_dev::kWfBlock * sizeof(uint32_t);  // closest-hit record + sentinel + stack
+    // closest-hit record + sentinel + stack (+ the keys and items of the leaf passes)
+    return ((size_t)(stack_levels + 1 + ptmi_dev::kHitWords) * ptmi_dev::kWfBlock + ptmi_dev::kLeafPassWords) * sizeof(uint32_t);
 }
 
 int wavefront_resident_blocks(int device, uint32_t stack_levels)
@@ -742,6 +930,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         warm.boxes_ordered = sc.boxes_ordered;
         warm.wide_records = sc.wide_records;
         warm.russian_roulette = sc.russian_roulette;
+        warm.wait_debt = lv >= 16u ? 768u : 512u;
 #define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
     hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
                        first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)
