@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     // All LDS traffic of a pass stays inside the wave (LDS operations of one wave execute in order): no barrier.
     unsigned long long* const key_mem = reinterpret_cast<unsigned long long*>(&stack_mem[(kHitWords + 1 + stack_levels) * kWfBlock]);
     uint2* const item_mem = reinterpret_cast<uint2*>(&stack_mem[(kHitWords + 3 + stack_levels) * kWfBlock]) + (tid & ~63u);
-    const uint32_t lane = tid & 63u, wave_first = tid & ~63u;
+    const uint32_t lane = tid & 63u, wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));  // (a scalar)
     uint32_t pass_rounds = 0, pass_items = 0;
     auto leaf_pass = [&](bool waits_at_leaf) {
         auto lanes_below = [&](unsigned long long m) {
