@@ -15,27 +15,34 @@
 //    the histograms in LDS.  (Jobs of one pixel x all iterations kept the sum in registers but left a tail of
 //    one whole job per lane: -12 % at 1080p.  Three global atomics per path for the histograms: -79 % on the
 //    Cornell box.)
-//  * Every lane is a small STATE MACHINE over the same three step kinds:
+//  * Every lane is a small STATE MACHINE over the same three kinds of work:
 //        I  one inner-node step  (load one 64-byte DNode, two slab tests, push/pop on the LDS stack)
-//        T  one triangle test    (load one 64-byte DTri)
+//        T  the triangles of a leaf (64-byte DTri records)
 //        P  path logic           (shade a finished closest-hit query, set up / account a shadow ray,
 //                                 scatter, finish the path, start the next iteration or fetch a new job)
-//    A camera segment and a shadow ray are the same I/T steps with another `limit` and exit rule, so lanes
+//    A camera segment and a shadow ray are the same I/T work with another `limit` and exit rule, so lanes
 //    in either phase, of any bounce, of any pixel, run together.
-//  * LOOP NEST: traversal trips in an inner loop - in a trip EVERY traversing lane takes one step, I or T,
-//    both fed by the same record loads - and a path-logic pass in the outer loop when the lanes waiting for
-//    it have waited long enough (wait debt) or nothing can traverse.
+//  * LOOP NEST: traversal trips in an inner loop, a path-logic pass in the outer loop when the lanes waiting for
+//    it have waited long enough (wait debt) or nothing can traverse.  A trip is either a NODE TRIP - every lane
+//    at an inner node takes one step - or a LEAF PASS: a lane that reaches a leaf waits, and when about nineteen
+//    lanes wait (or more triangles than there are lanes left at inner nodes) the next <= 64 triangles of all
+//    waiting leaves are dealt out one per lane to ALL lanes of the wave, whatever their own state; the owner's ray
+//    comes through the cross-lane network (ds_bpermute), the results go back through one 64-bit LDS minimum per
+//    owner.  Triangle tests run at 96 % lane utilisation (a leaf of 3 triangles: one pass instead of three trips
+//    under a 30 % exec mask); node trips at 66 %.  (PTMI_WF_LEAF_PASS=0 builds round 1's mixed trips, where every
+//    traversing lane takes one step per trip, node or triangle.)
 //  * Per ray the visit sequence is exactly the reference's (near child first, far child pushed, leaf
 //    triangles in index order, limit updated between tests, FullKernel.cl:620-702): only WHEN a lane
-//    takes its next step changes, never WHICH step it takes.  Results are bit-identical to the
-//    one-path-per-lane kernel (kernels.hip) and to the CPU checker.
+//    takes its next step changes, never WHICH tests it makes or what they see (see leaf_pass for the one place
+//    where tests of one ray run side by side).  Results are bit-identical to the one-path-per-lane kernel
+//    (kernels.hip) and to the CPU checker.
 //
 // Exit: a lane dies when it has seen every queue empty; a wave leaves the outer loop when no lane is alive
 // (every path is bounded by the ray depth, every traversal by the finite tree, and a pass or trip only runs
 // with at least one lane that wants it).
 //
-// The kernel's limits, measured: DESIGN.md 5 "What binds" (VALU issue, L1 access rate and L1-miss line rate
-// within 20 % of each other).  tools/isa_trip.sh prints the instruction mix of the traversal loop.
+// The kernel's limits, measured: DESIGN.md 5 "What binds".  tools/isa_trip.sh prints the instruction mix of the
+// traversal loop.
 #include <hip/hip_runtime.h>
 
 #include "ptmi_device.hpp"
@@ -609,6 +616,11 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         if (STATS) { trips_p++; lanes_p += n_p; }
         const unsigned long long pass_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         // (three divergent regions with the wave-uniform job hand-out between them: the queue state must stay scalar)
+        // A shadow ray, a scattered ray and a camera ray all end in the same ray set-up (a normalisation and three divisions)
+        // and the same start of a query: their sources leave the direction here and ONE copy at the end of the pass serves
+        // the three (a lane has at most one new ray per pass).
+        bool new_ray = false;
+        V4 new_direction = v4(0, 0, 0, 0);
         if (want_post) {
             need_path = cur == REF_IDLE;
             alive = true;
@@ -653,14 +665,16 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     }
                     if (do_scatter) {
                         r.d = cam_d;
-                        radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
+                        V4 out;
+                        radiance = radiance + scatter_direction(r, seed, in_water, sf, direct, transfer, out);
+                        r.o = hit.point + out * 0.001f;  // :880 uses the un-normalised direction
                         reflection++;
                         shadow = false;
                         if (!path_continues(transfer, reflection, seed, sc.russian_roulette != 0) || reflection >= sc.max_depth) {  // :1296-1314, :1248
                             end_path = true;
                         } else {
                             limit = INFINITY;
-                            start_query();
+                            new_direction = out; new_ray = true;
                         }
                     }
                 }
@@ -671,10 +685,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     const bool directional = light.type == PTMI_LIGHT_DIRECTIONNAL;
                     const V4 full = directional ? -v4(light.direction) : v4(light.position) - hit.point;
                     r.o = hit.point;
-                    ray_set_direction(r, full);
                     limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
                     shadow = true;
-                    start_query();
+                    new_direction = full; new_ray = true;
                 }
                 if (end_path) finish_path(missed);
             }
@@ -734,7 +747,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 {
                     const DScene& cs = cold_scene();  // camera: only needed here, once per path
                     r.o = v4(cs.cam_pos);
-                    ray_set_direction(r, (v4(cs.cam_dir) + (v4(cs.cam_right) * sample_x)) + (v4(cs.cam_up) * sample_y));
+                    new_direction = (v4(cs.cam_dir) + (v4(cs.cam_right) * sample_x)) + (v4(cs.cam_up) * sample_y);
                 }
                 radiance = v4(0, 0, 0, 0);
                 transfer = v4(1, 1, 1, 1);
@@ -761,10 +774,14 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 } else
                 if (sc.max_depth > 0) {
                     limit = INFINITY;
-                    start_query();
+                    new_ray = true;
                 } else {
                     finish_path(false);  // depth 0: the bounce loop never runs (:1248), radiance 0, depth bin 0
                 }
+            }
+            if (new_ray) {
+                ray_set_direction(r, new_direction);
+                start_query();
             }
             if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
         }

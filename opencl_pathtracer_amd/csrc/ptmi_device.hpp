@@ -406,16 +406,18 @@ __device__ __forceinline__ V4 cosine_sample_hemisphere(int& seed, V4 N)
     const float u2 = lcg_random(seed);
     const float sx = 2 * u1 - 1;
     const float sy = 2 * u2 - 1;
-    float r, theta;
+    // The reference's four octant pairs (:356-397), each with a division of its own:
+    //   sx > -sy:  sx > sy ? (r = sx, theta = sy > 0 ? sy/sx : 8 + sy/sx) : (r = sy, theta = 2 - sx/sy)
+    //   else:      sx < sy ? (r = -sx, theta = 4 + sy/sx)                 : (r = -sy, theta = 6 - sy/sx)
+    // written with ONE division whose operands are selected (the lanes of a wave fall into all four branches, so the
+    // branchy form executes every copy of the ~10-instruction division): same operations per lane, same bits.
+    const bool upper = sx > -sy;
+    const bool pair_a = upper & (sx > sy), pair_b = upper & !(sx > sy), pair_c = !upper & (sx < sy);
+    const float q = (pair_b ? sx : sy) / (pair_b ? sy : sx);
+    float r = pair_a ? sx : (pair_b ? sy : (pair_c ? -sx : -sy));
+    float theta = pair_a ? (sy > 0 ? q : 8.f + q) : (pair_b ? 2.f - q : (pair_c ? 4.f + q : 6.f - q));
+    if (fabsf(sy) < 0.0001f) { r = sx; theta = 2; }
     if (fabsf(sx) < 0.0001f) { r = sy; theta = 0; }
-    else if (fabsf(sy) < 0.0001f) { r = sx; theta = 2; }
-    else if (sx > -sy) {
-        if (sx > sy) { r = sx; theta = sy > 0 ? sy / sx : 8.f + sy / sx; }
-        else { r = sy; theta = 2.f - sx / sy; }
-    } else {
-        if (sx < sy) { r = -sx; theta = 4.f + sy / sx; }
-        else { r = -sy; theta = 6.f - sy / sx; }
-    }
     theta *= kPi / 4.f;
     r = (float)((double)r * 0.999);  // FullKernel.cl:408: the literal is a double
     float sn, cs;

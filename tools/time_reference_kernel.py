@@ -41,6 +41,14 @@ ms, _ = be.kernel_time()
 color, count = be.read_image()
 c = be.counters()
 dep, _, _ = be.read_statistics()
+# the integrator's own launch size: 32 iterations per launch (what OpenCL_RunKernel's loop gets through ptmi_render_snapshots
+# and what bench.py times); the reference's rate does not depend on the count - it is one launch per iteration either way
+be.clear()
+be.kernel_time()
+be.render(0, 32)
+be.synchronize()
+ms32, _ = be.kernel_time()
+c32 = be.counters()
 be.release()
 
 rms = cases.rms_per_channel(color, count, r_color, r_count)
@@ -50,6 +58,9 @@ out = {"case": case, "spp": spp,
                             "Msamples/s_upper_bound": seg_ref / ref_ms / 1e3},
        "this_integrator": {"kernel_ms_total": ms, "Mpaths/s": c["paths"] / ms / 1e3, "Msamples/s": c["segments"] / ms / 1e3},
        "speedup_paths": (c["paths"] / ms) / (w * h * spp / ref_ms),
+       "this_integrator_32_iterations_per_launch": {"kernel_ms_total": ms32, "Mpaths/s": c32["paths"] / ms32 / 1e3,
+                                                    "Msamples/s": c32["segments"] / ms32 / 1e3},
+       "speedup_paths_32_iterations_per_launch": (c32["paths"] / ms32) / (w * h * spp / ref_ms),
        "rms_per_channel_vs_reference": rms.tolist(),
        "depth_histogram_L1": int(np.abs(dep.astype(np.int64) - r_dep.astype(np.int64)).sum()), "paths": int(dep.sum())}
 print(json.dumps(out))
