@@ -254,11 +254,17 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     auto finish_path = [&](bool missed) {
         // totals of the launch (ptmi_get_counters): added per finished path into the workgroup's LDS block - everything is
         // a function of the three per-path counters, so no lane keeps running totals in registers
-        atomicAdd(&block_counters[C_PATHS], 1ull);
-        atomicAdd(&block_counters[C_HITS], (unsigned long long)reflection);
-        atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)(reflection + (missed ? 1u : 0u)));
-        atomicAdd(&block_counters[C_BBX], (unsigned long long)p_bbx);
-        atomicAdd(&block_counters[C_TRI], (unsigned long long)p_tri);
+        // (the index goes through an opaque asm so that the compiler does not see a wave-uniform address: for those it sums
+        // the lanes in a scalar loop first - five loops on the critical path of a pass in which two or three lanes finish.
+        // Plain LDS atomics: 1M triangles +0.2 %, Cornell box +4.1 %, material mix +1.6 %)
+        uint32_t none = 0;
+        asm volatile("" : "+v"(none));
+        unsigned long long* const totals = &block_counters[none];
+        atomicAdd(&totals[C_PATHS], 1ull);
+        atomicAdd(&totals[C_HITS], (unsigned long long)reflection);
+        atomicAdd(&totals[C_SEGMENTS], (unsigned long long)(reflection + (missed ? 1u : 0u)));
+        atomicAdd(&totals[C_BBX], (unsigned long long)p_bbx);
+        atomicAdd(&totals[C_TRI], (unsigned long long)p_tri);
         if (sc.histograms && stage_stats == nullptr) {
             // RANDOM sampler / very deep paths: the three statistics atomics as the reference issues them (:1319-1331)
             const DScene& cs = cold_scene();

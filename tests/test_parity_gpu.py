@@ -123,6 +123,27 @@ def test_degenerate_trees_and_big_leaves(kernel, scene_factory):
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
+def test_leaf_order_with_exact_ties(kernel, scene_factory):
+    """Triangles of one leaf at EXACTLY the same distance: the reference's leaf loop accepts a hit whose squared distance
+    equals the limit (`> limit` rejects, FullKernel.cl:560), so the LAST of several coincident triangles wins and a shadow
+    query stops counting at the FIRST.  A panel stored several times over with a different material each time - a leaf of
+    4 triangles, and leaves of 6 and 7 that a leaf pass of the wavefront kernel takes in two parts - shows the winner in
+    the image and the stop in the triangle-test histogram."""
+    from opencl_pathtracer_amd import scenes
+    base = scenes.cornell_box(48, 32)
+    walls = base.triangulation[:10]
+    quad = np.array([[[150, 180, 120], [430, 200, 130], [400, 260, 400]], [[150, 180, 120], [400, 260, 400], [170, 250, 380]]], np.float32)
+    for n_tris, copies in ((2, 2), (1, 6), (1, 7)):
+        panels = [scenes.triangle_create(quad[:n_tris, 0], quad[:n_tris, 1], quad[:n_tris, 2], mat_pos=k % 3) for k in range(copies)]
+        sc = _custom_scene(scenes._concat_tris([walls.copy()] + panels), base)
+        assert sc.bvh["nbTriangles"][sc.bvh["isLeaf"] != 0].max() == n_tris * copies  # the copies share one leaf
+        color, count, (dep, bbx, tri), counters = render_scene(sc, 48, 32, 4, 4, flags=KERNELS[kernel])
+        o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 48, 32, 4, 4)
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and counters == totals, copies
+        assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri), copies
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 def test_russian_roulette_mode_vs_oracle(kernel, scene_factory):
     """PTMI_FLAG_RUSSIAN_ROULETTE: the termination block the reference ships commented out (FullKernel.cl:1306-1314), as
     written there - a non-parity mode (images differ from the reference's), bit-exact against the oracle's same switch."""
