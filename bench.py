@@ -32,10 +32,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
-# tools/microbench/record_fetch.hip on MI355X (profiles/r01_ab_late_round.txt): random 64-byte records, per-lane 4 x dwordx4,
-# G records/s chip-wide when the set sits in the L2s / in the Infinity Cache
-RECORD_FETCH_L2 = 214.5e9
-RECORD_FETCH_MALL = 56.8e9
+# What the 256 L1s (TCP) of the chip take, measured with tools/microbench on MI355X (profiles/r01_ab_late_round.txt),
+# independent of occupancy from 2 to 8 waves per SIMD:
+#   accesses: random 64-byte records read with four dwordx4 loads per lane, set resident in the L2s: 214.5 G records/s x 4
+#   line fills: random 32-byte records (one new line per record): 258 G/s from the L2s, 58 G/s from the Infinity Cache
+L1_ACCESS_RATE = 4 * 214.5e9
+L1_FILL_RATE_L2 = 258.2e9
+L1_FILL_RATE_MALL = 58.1e9
 
 
 def algorithmic_bytes(c, n_pixels, n_flush):
@@ -258,7 +261,8 @@ def committed_pmc(args, W, H, D, B):
 
 def binding_ceilings(pmc, launch_s, records_per_launch):
     """traffic = memory-side bytes per launch (FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes for
-    16-byte-per-lane loads, plus WRITE_SIZE), and the three ceilings the kernel runs into, each as a fraction <= 1."""
+    16-byte-per-lane loads, plus WRITE_SIZE), and the ceilings the kernel runs against, each as a fraction <= 1: VALU issue,
+    L2 request bandwidth, and the L1s' access and line-fill rates."""
     v = lambda k: pmc[k]["per_launch_mean"] if k in pmc else None
     out = {"traffic_source": pmc["_path"] + " (PMC passes of this command, committed; not measured in this run)"}
     if v("FETCH_SIZE") is not None and v("WRITE_SIZE") is not None:
@@ -278,12 +282,16 @@ def binding_ceilings(pmc, launch_s, records_per_launch):
         binding["l2_requests"] = {"achieved": req / launch_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
                                   "frac": req / launch_s / 1e9 / L2_PEAK_GBS,
                                   "hit_rate": v("TCC_HIT_sum") / (v("TCC_HIT_sum") + v("TCC_MISS_sum"))}
-        # record-fetch ceiling for this scene's split between L2 hits and lines from the Infinity Cache / HBM
-        # (tools/microbench/record_fetch): time = hits / rate_L2 + misses / rate_MALL, in records of 64 bytes
         hit = v("TCC_HIT_sum") / (v("TCC_HIT_sum") + v("TCC_MISS_sum"))
-        t_min = records_per_launch * (hit / RECORD_FETCH_L2 + (1.0 - hit) / RECORD_FETCH_MALL)
-        binding["record_fetch"] = {"achieved": records_per_launch / launch_s / 1e9, "peak": records_per_launch / t_min / 1e9,
-                                   "unit": "G records/s", "frac": t_min / launch_s}
+        if v("TCP_TOTAL_CACHE_ACCESSES_sum") is not None and v("TCP_TCC_READ_REQ_sum") is not None:
+            # the two rates at which the L1s work: lane accesses (one per lane per load instruction for this gather) and
+            # line fills, the latter for this scene's split between fills from the L2s and from the Infinity Cache / HBM
+            acc, fills = v("TCP_TOTAL_CACHE_ACCESSES_sum"), v("TCP_TCC_READ_REQ_sum")
+            binding["l1_accesses"] = {"achieved": acc / launch_s / 1e9, "peak": L1_ACCESS_RATE / 1e9, "unit": "G accesses/s",
+                                      "frac": acc / launch_s / L1_ACCESS_RATE, "per_record": acc / records_per_launch}
+            t_min = fills * (hit / L1_FILL_RATE_L2 + (1.0 - hit) / L1_FILL_RATE_MALL)
+            binding["l1_line_fills"] = {"achieved": fills / launch_s / 1e9, "peak": fills / t_min / 1e9, "unit": "G lines/s",
+                                        "frac": t_min / launch_s, "per_record": fills / records_per_launch}
     if v("SQ_WAVE_CYCLES") is not None and v("SQ_WAIT_ANY") is not None:
         binding["wave_cycles"] = {"waiting": v("SQ_WAIT_ANY") / v("SQ_WAVE_CYCLES"),
                                   "issue_stalled": (v("SQ_WAIT_INST_ANY") or 0.0) / v("SQ_WAVE_CYCLES"),

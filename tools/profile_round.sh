@@ -9,7 +9,7 @@ TAG=${1:?tag}; shift
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o wf -- python3 $R/bench.py --no-cpu-baseline --no-boundary "$@" > $R/gpurun_out/bench_prof_$TAG.log 2>&1
-for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-20)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -o $n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-boundary "$@" > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1 || echo "pmc pass '$c' failed"
   echo "pass $n done"

@@ -13,3 +13,4 @@ cp $G/prof_r02_tris1m/wf_kernel_stats.csv $P/r02_wavefront_kernel_stats_tris1m.c
 cp $G/prof_r02_tris4m/wf_kernel_stats.csv $P/r02_wavefront_kernel_stats_tris4m.csv
 cp $G/r02_north_star_rms.json $P/r02_north_star_rms.json
 ls -la $P | grep r02
+# (TCP_* counters: tools/profile_round.sh collects them as one more group; merged by key into the same json)
