@@ -77,6 +77,26 @@ def test_bit_exact_vs_reference_strict_build(case, scene_factory):
     assert len(bad) == 0, f"{len(bad)} channel values differ from the reference's strict build, first at {bad[:5].tolist()}"
 
 
+FULL_SIZE = {"tris1m_1920x1080_d10": ("tris1m", S.JITTERED, 1920, 1080, 10, 2),   # BASELINE configs[2]: the bench workload
+             "cornell_1920x1080_d8": ("cornell", S.JITTERED, 1920, 1080, 8, 4)}     # BASELINE configs[1]
+
+
+@pytest.mark.parametrize("case", list(FULL_SIZE))
+def test_full_size_bit_exact_vs_reference_strict_build(case):
+    """BASELINE's own image size, scene and ray depth: every one of the 2 M pixels, the sample counts and the three
+    histograms of the default (wavefront) kernel equal the reference kernel's strict build run beside it on this GPU."""
+    if not O.have_ref_kernel(case, strict=True):
+        pytest.skip("oracle/_ref strict code object not present (built only where the reference tree exists)")
+    name, sampler, w, h, d, spp = FULL_SIZE[case]
+    sc = bvh_create(scenes.build(name, w, h))
+    r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, spp, strict=True)
+    color, count, (dep, bbx, tri), _ = render_scene(sc, w, h, d, spp, sampler=sampler)
+    assert np.array_equal(count, r_count)
+    assert np.array_equal(dep, r_dep) and np.array_equal(bbx, r_bbx) and np.array_equal(tri, r_tri)
+    bad = np.argwhere(color.view(np.uint32) != r_color.view(np.uint32))
+    assert len(bad) == 0, f"{len(bad)} channel values differ from the reference's strict build, first at {bad[:5].tolist()}"
+
+
 @pytest.mark.parametrize("feature", scenes.FEATURES)
 def test_every_feature_bit_exact_vs_reference_strict_build(feature):
     """One kernel feature per scene (materials, textures, light types, sky, two-sided / fallback normals), 256 spp: 1M paths
