@@ -272,11 +272,16 @@ def binding_ceilings(pmc, launch_s, records_per_launch):
                                "frac": traffic / launch_s / 1e9 / HBM_PEAK_GBS}
     binding = {}
     if v("SQ_INSTS_VALU") is not None:
-        # a wave64 VALU instruction holds its SIMD's issue port for 4 cycles; cycles of the launch from GRBM_GUI_ACTIVE
-        # (summed over the 8 XCDs) where collected, else at the 2.4 GHz maximum clock
+        # cycles of the launch from GRBM_GUI_ACTIVE (summed over the 8 XCDs) where collected, else at the 2.4 GHz maximum
+        # clock.  What a wave64 VALU instruction costs its SIMD, measured (tools/microbench/pk_rate.hip): 2 cycles for plain
+        # 32-bit operations (v_fma_f32, v_mul_f32, v_add_u32, v_mov_b32), 4 for packed fp32, 64-bit integer, three-operand
+        # min / max, compares into SGPRs and v_mbcnt, 8 for v_rcp_f32.  No counter of this chip separates the classes, so
+        # `frac` prices every instruction at 4 cycles - an UPPER bound of how busy the VALUs are - and `frac_if_all_2_cycles`
+        # is the lower bound.
         cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
         binding["valu_issue"] = {"achieved": v("SQ_INSTS_VALU") * 4.0 / N_SIMD, "peak": cycles, "unit": "cycles per SIMD per launch",
-                                 "frac": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles}
+                                 "frac": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles,
+                                 "frac_if_all_2_cycles": v("SQ_INSTS_VALU") * 2.0 / N_SIMD / cycles}
     if v("TCC_HIT_sum") is not None and v("TCC_MISS_sum") is not None:
         req = (v("TCC_HIT_sum") + v("TCC_MISS_sum")) * 64.0
         binding["l2_requests"] = {"achieved": req / launch_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",

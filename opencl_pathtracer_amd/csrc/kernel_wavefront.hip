@@ -435,18 +435,17 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             h2 = box_hit(lo2, hi2, (ref2 & REF_EMPTY) != 0, r, limit);
         }
         p_bbx += 2;
-        const uint32_t far_ref = fwd ? ref2 : ref1;
-        const bool both = h1 & h2;
-        sp[kWfBlock] = far_ref;
-        sp += both ? kWfBlock : 0;
-        cur = fwd ? (h1 ? ref1 : ref2) : (h2 ? ref2 : ref1);
-        {
-            const bool need_pop = !(h1 | h2);
-            const uint32_t popped = *sp;
-            uint32_t* const under = sp - kWfBlock;
-            cur = need_pop ? popped : cur;
-            sp = need_pop ? (under < stack_floor ? stack_floor : under) : sp;
-        }
+        // (every choice as a select on the two hit masks themselves: combined into new booleans first - both, neither - the
+        // compiler builds them as 0 / 1 integers in vector registers: seven instructions more per step)
+        sp[kWfBlock] = fwd ? ref2 : ref1;
+        uint32_t* const pushed = sp + kWfBlock;
+        sp = h1 ? (h2 ? pushed : sp) : sp;
+        const uint32_t popped = *sp;
+        uint32_t* const below = sp - kWfBlock;
+        uint32_t* const under = below < stack_floor ? stack_floor : below;
+        const uint32_t child = fwd ? (h1 ? ref1 : ref2) : (h2 ? ref2 : ref1);  // near child if it was hit, else the far one
+        cur = h1 ? child : (h2 ? child : popped);
+        sp = h1 ? sp : (h2 ? sp : under);
         if (cur != REF_NONE && (cur & REF_LEAF)) {  // (the triangle range of a lane that takes node steps is free)
             decode_leaf(sc, cur, tri_i, tri_end);
             cur = *sp;
@@ -478,6 +477,11 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         want_post = !pending & !has_node & (cur != REF_DEAD);
         any_lane = (m_t | m_i | m_p) != 0ull;
         n_t = __popcll(m_t); n_i = __popcll(m_i); n_p = __popcll(m_p);
+        // (scalars, and to stay scalars: left alone the compiler decides what the next trip is with packed 16-bit VECTOR
+        // multiplies.  Going further - the two decisions as integer max / min arithmetic the loop branches on - measured
+        // slower, 924 -> 916 Msamples/s: the scalar unit of a CU is ~45 % busy in this kernel and a scalar instruction more
+        // per trip costs more than a plain vector one, tools/microbench/pk_rate.hip and DESIGN.md 5.)
+        if (kLeafPass) asm volatile("" : "+s"(n_t), "+s"(n_i));
         wait_debt += n_p;
     };
     // path logic is due / nothing can traverse (then every waiting lane is served)
