@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     bool exact_boxes = false;  // this ray needs the literal box test (see box_hit_ordered)
     bool wave_exact = true;    // ... and so does some ray of this wave (wave-uniform, refreshed after every path-logic pass)
     uint32_t cur = REF_IDLE, tri_i = 0, tri_end = 0;
+    uint32_t dir_signs = 0;  // bit k: direction component k > 0 (which child of a node cut along k is the near one)
     uint32_t* sp = stack_floor;  // the top entry (the sentinel when the stack is empty)
     // the point of the closest hit, as path logic needs it when a query has finished
     auto load_hit_point = [&]() {
@@ -424,8 +425,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         const float lo1[3] = {a.x, a.y, a.z}, hi1[3] = {a.w, b.x, b.y};
         const float lo2[3] = {b.z, b.w, c.x}, hi2[3] = {c.y, c.z, c.w};
         const uint32_t ref1 = __float_as_uint(d.x), ref2 = __float_as_uint(d.y), axis = __float_as_uint(d.z);
-        const bool a0 = axis == 0, a1 = axis == 1;
-        const bool fwd = (a0 & (r.d.x > 0)) | (a1 & (r.d.y > 0)) | (!(a0 | a1) & (r.d.z > 0));
+        // dir[cutAxis] > 0 (:663) from a per-ray word of the three signs (one bit test; selected from the three sign masks
+        // the box tests hold it took three compares and five scalar instructions)
+        const bool fwd = ((dir_signs >> axis) & 1u) != 0;
         bool h1, h2;
         if (!wave_exact) {
             h1 = box_hit_ordered(lo1, hi1, r, limit);
@@ -467,11 +469,11 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     bool pending, want_inner, want_post;
     int n_t, n_i, n_p;
     bool any_lane;
+    unsigned long long dead_lanes = 0ull;  // (lanes only die in path logic: the mask is taken there)
     auto survey = [&]() {
         pending = tri_i < tri_end;
         const bool has_node = cur < REF_DEAD;
-        const unsigned long long b_t = __builtin_amdgcn_ballot_w64(pending), b_n = __builtin_amdgcn_ballot_w64(has_node),
-                                 b_dead = __builtin_amdgcn_ballot_w64(cur == REF_DEAD);
+        const unsigned long long b_t = __builtin_amdgcn_ballot_w64(pending), b_n = __builtin_amdgcn_ballot_w64(has_node), b_dead = dead_lanes;
         const unsigned long long m_t = b_t, m_i = b_n & ~b_t, m_p = ~(b_t | b_n | b_dead);
         want_inner = !pending & has_node;
         want_post = !pending & !has_node & (cur != REF_DEAD);
@@ -791,10 +793,12 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             }
             if (new_ray) {
                 ray_set_direction(r, new_direction);
+                dir_signs = (r.d.x > 0 ? 1u : 0u) | (r.d.y > 0 ? 2u : 0u) | (r.d.z > 0 ? 4u : 0u);
                 start_query();
             }
             if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
         }
+        dead_lanes = __builtin_amdgcn_ballot_w64(cur == REF_DEAD);
         wave_exact = __builtin_amdgcn_ballot_w64(exact_boxes) != 0ull;  // finished lanes keep a stale flag: conservative
         if (STATS) cycles_p += __builtin_amdgcn_s_memtime() - pass_start;
     }
