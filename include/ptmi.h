@@ -113,8 +113,8 @@ typedef struct ptmi_counters {
  * SIMD utilisation of that kind).  Collected only with PTMI_FLAG_SCHEDULER_STATS; all zero otherwise and for the
  * one-path-per-lane kernel. */
 typedef struct ptmi_scheduler_stats {
-    uint64_t trips_node, lanes_node;         /* inner-node steps */
-    uint64_t trips_triangle, lanes_triangle; /* triangle tests */
+    uint64_t trips_node, lanes_node;         /* node trips: lanes that took an inner-node step */
+    uint64_t trips_triangle, lanes_triangle; /* leaf passes: triangles tested, one per lane */
     uint64_t trips_path, lanes_path;         /* path logic (shade / shadow set-up / scatter / regenerate) */
     uint64_t cycles_path, cycles_loop;       /* shader-clock cycles, summed over waves: inside path-logic passes / in the main loop */
 } ptmi_scheduler_stats;
