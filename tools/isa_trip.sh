@@ -1,6 +1,9 @@
 #!/bin/bash
-# Static instruction mix of the traversal trip of render_wavefront_kernel<false,true,false> (the shipped
-# specialisation): the kernel is VALU-issue bound, so VALU instructions per trip are what every edit is judged by.
+# Static instruction mix of the traversal loop (node trips + leaf passes) of render_wavefront_kernel<false,true,false>, the
+# shipped specialisation.  Both the vector and the scalar instructions of a trip are paid for (DESIGN.md 5 "What binds":
+# plain 32-bit VALU operations cost 2 cycles, packed / 64-bit / compare-to-SGPR ones 4, and the one scalar unit of a CU is
+# ~45 % busy), so every edit of the loop is judged by both counts - and by a same-box A/B, the compiler's register
+# allocation being what it is.
 # usage: tools/isa_trip.sh [extra hipcc flags]   -> /tmp/isa/k.s plus a summary
 set -e
 mkdir -p /tmp/isa
