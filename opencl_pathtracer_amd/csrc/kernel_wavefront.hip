@@ -158,7 +158,9 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
     tri_end = start + count;
 }
 
-template <bool STATS, bool PRE, bool SS>
+// PLAIN: path logic for scenes of plain-colour MAT_STANDART materials and LIGHT_POINT lights only (DScene::plain_shading):
+// the same operations for those scenes, without the code - and the registers - of the other material and light types.
+template <bool STATS, bool PRE, bool SS, bool PLAIN = false>
 __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t iteration_stride,
@@ -669,9 +671,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     hit.tri = w6 & REF_INDEX_MASK_LEAF; hit.front = (w6 & kHitFront) != 0;
                     Ray arrival;
                     arrival.o = hit.point; arrival.d = cam_d; arrival.ix = arrival.iy = arrival.iz = 0;
-                    load_surface(sc, arrival, hit, sf);
+                    load_surface<PLAIN>(sc, arrival, hit, sf);
                     if (lit) {
-                        const ptmi_light light = sc.lights[light_idx];
+                        ptmi_light light = sc.lights[light_idx];
+                        if (PLAIN) light.type = PTMI_LIGHT_POINT;
                         const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
                         direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
                     }
@@ -694,7 +697,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 if (start_shadow) {
                     // :932-944: ray from the hit point (no offset) towards light `light_idx`
                     const ptmi_light light = sc.lights[light_idx];
-                    const bool directional = light.type == PTMI_LIGHT_DIRECTIONNAL;
+                    const bool directional = !PLAIN && light.type == PTMI_LIGHT_DIRECTIONNAL;
                     const V4 full = directional ? -v4(light.direction) : v4(light.position) - hit.point;
                     r.o = hit.point;
                     limit = directional ? INFINITY : length(full);  // LINEAR distance in the squared slot
@@ -962,20 +965,23 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         warm.wide_records = sc.wide_records;
         warm.russian_roulette = sc.russian_roulette;
         warm.wait_debt = lv >= 16u ? 768u : 512u;
-#define PTMI_LAUNCH_WF_IMPL(S, P, A)                                                                                 \
-    hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A>), g, b, lds, st, scene_in_device_memory, warm,    \
+#define PTMI_LAUNCH_WF_IMPL(S, P, A, L)                                                                              \
+    hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A, L>), g, b, lds, st, scene_in_device_memory, warm, \
                        first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)
 #define PTMI_LAUNCH_WF(S, P, A)                                                                                       \
-    PTMI_LAUNCH_WF_IMPL(S, P, A)
+    PTMI_LAUNCH_WF_IMPL(S, P, A, false)
         // instantiations: the common case (no statistics, no adaptive sampling) pays for neither
         if (sc.super_sampling) {
             if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, true); else PTMI_LAUNCH_WF(true, false, true);
         } else if (scheduler_stats) {
             if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false); else PTMI_LAUNCH_WF(true, false, false);
         } else {
-            if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false); else PTMI_LAUNCH_WF(false, false, false);
+            if (sc.tris_precomputed && sc.plain_shading) PTMI_LAUNCH_WF_IMPL(false, true, false, true);
+            else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false);
+            else PTMI_LAUNCH_WF(false, false, false);
         }
 #undef PTMI_LAUNCH_WF
+#undef PTMI_LAUNCH_WF_IMPL
         e = hipGetLastError();
     }
     if (e != hipSuccess) {

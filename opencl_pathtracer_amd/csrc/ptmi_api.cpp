@@ -191,6 +191,7 @@ struct Relayout {
     std::vector<DMat> mats;
     std::vector<DBigLeaf> big_leaves;
     bool tris_precomputed = false;
+    bool plain_shading = false; // every material a plain-colour MAT_STANDART, every light a LIGHT_POINT
     bool boxes_ordered = true;  // all non-empty child boxes finite with pMin <= pMax
     uint32_t root_ref = 0;
     uint32_t max_depth = 0;
@@ -236,6 +237,13 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         d.type = m.type;
         d.is_simple_color = m.is_simple_color ? 1u : 0u;
     }
+    // The common untextured Lambert scene (BASELINE's Cornell box and 1M-triangle scene): the wavefront kernel has a
+    // specialisation whose path logic holds neither the other four material types nor textures nor the other light types.
+    out.plain_shading = std::getenv("PTMI_GENERIC_SHADING") == nullptr;  // developer switch for A/B runs and tests
+    for (uint32_t i = 0; i < sc->materiaux_size && out.plain_shading; i++)
+        if (sc->materiaux[i].type != PTMI_MAT_STANDART || !sc->materiaux[i].is_simple_color) out.plain_shading = false;
+    for (uint32_t i = 0; i < sc->lights_size && out.plain_shading; i++)
+        if (sc->lights[i].type != PTMI_LIGHT_POINT) out.plain_shading = false;
 
     out.tris.resize(nt);
     out.shade.resize(nt);
@@ -456,6 +464,7 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     std::memcpy(ds.cam_up, &sc->camera_up, 16);
     d.resident_blocks = wavefront_resident_blocks(d.device, ctx->stack_levels);
     ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
+    ds.plain_shading = lay.plain_shading ? 1u : 0u;
     ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
     ds.root_ref = lay.root_ref;
     ds.width = ctx->cfg.image_width;

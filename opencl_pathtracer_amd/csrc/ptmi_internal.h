@@ -128,6 +128,7 @@ struct DScene {
     uint32_t sampler;
     uint32_t super_sampling;  // -D SUPER_SAMPLING
     uint32_t tris_precomputed; // tris[] holds DTriPre records
+    uint32_t plain_shading;    // every material a plain-colour MAT_STANDART and every light a LIGHT_POINT
     uint32_t n_records;        // nodes + leaf triangles in the one record array (nodes == tris)
     uint32_t wide_records;     // that array is 4 GB or more: byte offsets need 64 bits
     uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)

@@ -12,7 +12,9 @@ struct Surface {
 
 // What Kernel_Main does between BVH_IntersectRay and the light loop
 // (FullKernel.cl:1254-1274) plus the deferred Triangle_GetColorValueAt (:591-602).
-template <class SceneT>
+// PLAIN: the scene holds only plain-colour MAT_STANDART materials (checked at upload): no texture fetch, and the type is a
+// constant for everything inlined behind this call.
+template <bool PLAIN = false, class SceneT>
 __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, const Hit& hit, Surface& sf)
 {
     const DShade* sh = &sc.shade[sc.tri_ids[hit.tri]];  // hit.tri is a record index
@@ -22,9 +24,10 @@ __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, con
     const V4 N1 = v4(s4[0]), N2 = v4(s4[1]), N3 = v4(s4[2]);
     const uint32_t mat_id = hit.front ? sh->mat_pos : sh->mat_neg;
     sf.mat = sc.mats[mat_id];
+    if (PLAIN) sf.mat.type = PTMI_MAT_STANDART;
 
     const float b = (1 - hit.s) - hit.t;
-    if (sf.mat.is_simple_color) {
+    if (PLAIN || sf.mat.is_simple_color) {
         sf.color = v4(sf.mat.color);
     } else {
         const float* uv = hit.front ? sh->uvp : sh->uvn;

@@ -350,6 +350,21 @@ def test_wide_record_addresses(scene_factory, monkeypatch):
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
 
 
+def test_plain_and_general_shading_specialisations(scene_factory, monkeypatch):
+    """A scene of plain-colour MAT_STANDART materials and LIGHT_POINT lights runs the wavefront kernel's plain-shading
+    specialisation; PTMI_GENERIC_SHADING=1 sends the same scene through the general one: both equal the oracle bit for bit
+    (the general specialisation is what every scene with textures, other materials or other lights runs anyway)."""
+    sc = scene_factory("cornell", 96, 64)
+    assert (sc.materiaux["type"] == S.MAT_STANDART).all() and sc.materiaux["isSimpleColor"].all() and (sc.lights["type"] == S.LIGHT_POINT).all()
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, 96, 64, 6, 5)
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("PTMI_GENERIC_SHADING", "1")
+        color, count, (dep, bbx, tri), counters = render_scene(sc, 96, 64, 6, 5)
+        assert counters == totals and np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri), generic
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count), generic
+
+
 def test_many_iterations_in_one_call_are_chunked(scene_factory):
     """ptmi_render splits a long range into launches of <= 32 iterations (staging array bound): same bits."""
     sc = scene_factory("cornell", 64, 48)
