@@ -158,9 +158,10 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
     tri_end = start + count;
 }
 
-// PLAIN: path logic for scenes of plain-colour MAT_STANDART materials and LIGHT_POINT lights only (DScene::plain_shading)
-// rendered with the JITTERED sampler and without Russian roulette: the same operations for those renders, without the code -
-// and the registers - of the other material types, light types and samplers (1M triangles +3.0 %, Cornell box +6.4 %).
+// PLAIN: path logic for scenes of plain-colour MAT_STANDART materials and ONE LIGHT_POINT (DScene::plain_shading) rendered
+// with the JITTERED sampler and without Russian roulette: the same operations for those renders, without the code - and
+// the registers - of the other material types, light types, samplers and of the light loop (1M triangles +4.9 %, Cornell
+// box +8.5 %).
 template <bool STATS, bool PRE, bool SS, bool PLAIN = false>
 __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc_arg, const uint32_t first_iteration,
@@ -173,9 +174,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
 {
     // traversal stacks: [level][lane], one dword per entry, as many levels as the tree is deep (the reference
     // reserves 30, FullKernel.cl:627; the deepest possible chain of pending far children is the tree depth)
-    // PLAIN also fixes the JITTERED sampler and no Russian roulette (the launch only picks it then): constants for the code below
+    // PLAIN also fixes the JITTERED sampler, no Russian roulette and ONE light (the launch only picks it then): constants below
     DWarm sc = sc_arg;
-    if (PLAIN) { sc.sampler = PTMI_SAMPLER_JITTERED; sc.russian_roulette = 0; }
+    if (PLAIN) { sc.sampler = PTMI_SAMPLER_JITTERED; sc.russian_roulette = 0; sc.n_lights = 1; }  // ... and ONE light
+    constexpr bool kOneLight = PLAIN;  // (nothing gathered across shadow queries, no light index: five registers fewer per lane)
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_mem[];
     __shared__ unsigned long long block_counters[C_COUNT];
 
@@ -653,8 +655,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     // closest-hit query finished (FullKernel.cl:1252-1288)
                     if (found) {
                         cam_d = r.d;
-                        direct = v4(0, 0, 0, 0);
-                        light_idx = 0;
+                        if (!kOneLight) {  // (one light: nothing is gathered across queries and the index is a constant)
+                            direct = v4(0, 0, 0, 0);
+                            light_idx = 0;
+                        }
                         if (sc.n_lights > 0) start_shadow = true;
                         else do_scatter = true;
                     } else {
@@ -664,7 +668,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 } else {
                     // shadow query finished (Scene_ComputeDirectIllumination, :944-947)
                     lit = !found;
-                    if (light_idx + 1u < sc.n_lights) start_shadow = true;
+                    if (!kOneLight && light_idx + 1u < sc.n_lights) start_shadow = true;
                     else do_scatter = true;
                 }
                 if (lit || do_scatter) {
@@ -676,16 +680,18 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     Ray arrival;
                     arrival.o = hit.point; arrival.d = cam_d; arrival.ix = arrival.iy = arrival.iz = 0;
                     load_surface<PLAIN>(sc, arrival, hit, sf);
+                    V4 gathered = kOneLight ? v4(0, 0, 0, 0) : direct;
                     if (lit) {
-                        ptmi_light light = sc.lights[light_idx];
+                        ptmi_light light = sc.lights[kOneLight ? 0u : light_idx];
                         if (PLAIN) light.type = PTMI_LIGHT_POINT;
                         const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
-                        direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
+                        gathered = gathered + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
+                        if (!kOneLight) direct = gathered;
                     }
                     if (do_scatter) {
                         r.d = cam_d;
                         V4 out;
-                        radiance = radiance + scatter_direction(r, seed, in_water, sf, direct, transfer, out);
+                        radiance = radiance + scatter_direction(r, seed, in_water, sf, gathered, transfer, out);
                         r.o = hit.point + out * 0.001f;  // :880 uses the un-normalised direction
                         reflection++;
                         shadow = false;
@@ -697,10 +703,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         }
                     }
                 }
-                if (shadow) light_idx++;  // (still set: this pass finished a shadow query and did not scatter)
+                if (!kOneLight && shadow) light_idx++;  // (still set: this pass finished a shadow query and did not scatter)
                 if (start_shadow) {
                     // :932-944: ray from the hit point (no offset) towards light `light_idx`
-                    const ptmi_light light = sc.lights[light_idx];
+                    const ptmi_light light = sc.lights[kOneLight ? 0u : light_idx];
                     const bool directional = !PLAIN && light.type == PTMI_LIGHT_DIRECTIONNAL;
                     const V4 full = directional ? -v4(light.direction) : v4(light.position) - hit.point;
                     r.o = hit.point;
@@ -980,7 +986,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         } else if (scheduler_stats) {
             if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false); else PTMI_LAUNCH_WF(true, false, false);
         } else {
-            if (sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette)
+            if (sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette && sc.n_lights == 1)
                 PTMI_LAUNCH_WF_IMPL(false, true, false, true);  // the common case, BASELINE's untextured scenes among them
             else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false);
             else PTMI_LAUNCH_WF(false, false, false);
