@@ -56,8 +56,11 @@ constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #ifndef PTMI_WF_WAIT_DEBT
 // lane-trips of waiting a wave tolerates before it spends a pass on path logic: a launch parameter (DWarm::wait_debt),
-// 512 for shallow trees, 768 from depth 16 on; PTMI_WF_WAIT_DEBT > 0 fixes it at build time for sweeps.
-// Measured on MI355X (Msamples/s: 1M triangles 1080p depth 20 / Cornell box 1080p d8 depth 5 / material mix 4K d16):
+// 768 from tree depth 16 on, below that 512 (general path logic) or 320 (plain scenes: the cheaper a pass, the sooner it
+// pays); PTMI_WF_WAIT_DEBT > 0 fixes it at build time for sweeps.
+// Measured on MI355X (Msamples/s: 1M triangles 1080p depth 22 / Cornell box 1080p d8 depth 5 / material mix 4K d16):
+//   round 2, plain-scene specialisation (first two scenes):  192: - / 6360 / 2193    256: - / 6620 / 2317    320: - / 6670 / 2403
+//                           384: - / 6600 / 2442    512: 960 / 6430 / 2491    640: 963 / 6190 / -    768: 976 / - / -    1024: 959 / - / -
 //   round 2, leaf passes:   512: 885 / 5388 / 2344    768: 895 / 5172 / 2314    1024: 895 / 5121 / 2235
 //   round 1, mixed trips:   256: - / 4883 / 1876    384: 733 / - / 1969    512: 740 / 4804 / 1986    768: 742 / 4896 / 1944
 //                           1024: 737 / 4845 / 1872    2048: - / 4840 / 1718
@@ -974,7 +977,9 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         warm.boxes_ordered = sc.boxes_ordered;
         warm.wide_records = sc.wide_records;
         warm.russian_roulette = sc.russian_roulette;
-        warm.wait_debt = lv >= 16u ? 768u : 512u;
+        const bool plain = sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette &&
+                           sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats;
+        warm.wait_debt = lv >= 16u ? 768u : (plain ? 320u : 512u);  // (the cheaper a path-logic pass, the sooner it pays)
 #define PTMI_LAUNCH_WF_IMPL(S, P, A, L)                                                                              \
     hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A, L>), g, b, lds, st, scene_in_device_memory, warm, \
                        first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)
@@ -986,8 +991,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         } else if (scheduler_stats) {
             if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false); else PTMI_LAUNCH_WF(true, false, false);
         } else {
-            if (sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette && sc.n_lights == 1)
-                PTMI_LAUNCH_WF_IMPL(false, true, false, true);  // the common case, BASELINE's untextured scenes among them
+            if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true);  // the common case, BASELINE's untextured scenes among them
             else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false);
             else PTMI_LAUNCH_WF(false, false, false);
         }
