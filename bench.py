@@ -262,7 +262,7 @@ def committed_pmc(args, W, H, D, B):
 def binding_ceilings(pmc, launch_s, records_per_launch):
     """traffic = memory-side bytes per launch (FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes for
     16-byte-per-lane loads, plus WRITE_SIZE), and the ceilings the kernel runs against, each as a fraction <= 1: VALU issue,
-    L2 request bandwidth, and the L1s' access and line-fill rates."""
+    the scalar unit, L2 request bandwidth, and the L1s' access and line-fill rates."""
     v = lambda k: pmc[k]["per_launch_mean"] if k in pmc else None
     out = {"traffic_source": pmc["_path"] + " (PMC passes of this command, committed; not measured in this run)"}
     if v("FETCH_SIZE") is not None and v("WRITE_SIZE") is not None:
@@ -282,6 +282,11 @@ def binding_ceilings(pmc, launch_s, records_per_launch):
         binding["valu_issue"] = {"achieved": v("SQ_INSTS_VALU") * 4.0 / N_SIMD, "peak": cycles, "unit": "cycles per SIMD per launch",
                                  "frac": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles,
                                  "frac_if_all_2_cycles": v("SQ_INSTS_VALU") * 2.0 / N_SIMD / cycles}
+    if v("SQ_INSTS_SALU") is not None:
+        # one scalar unit per CU (256 of them), one instruction per cycle at best
+        cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
+        binding["scalar_unit"] = {"achieved": v("SQ_INSTS_SALU") / 256.0, "peak": cycles, "unit": "instructions per CU per launch",
+                                  "frac": v("SQ_INSTS_SALU") / 256.0 / cycles}
     if v("TCC_HIT_sum") is not None and v("TCC_MISS_sum") is not None:
         req = (v("TCC_HIT_sum") + v("TCC_MISS_sum")) * 64.0
         binding["l2_requests"] = {"achieved": req / launch_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
