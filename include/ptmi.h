@@ -78,6 +78,13 @@ typedef struct ptmi_config {
                                          whose largest transfer component / (bounce - 5) is below 1 draws a random number, ends unless it
                                          exceeds that coefficient, and has its transfer divided by it.  Images differ from the reference's. */
 
+#define PTMI_FLAG_DEFAULT_ARITHMETIC 16u /* The arithmetic of the build the reference's own build line produces (OpenCL_BuildOptions,
+                                         OpenCL.cpp:292-314, passes no floating-point option): a*b+c written in one expression is one
+                                         fused multiply-add, a/b goes through v_rcp_f32 of the divisor's mantissa (2.5 ulp), sqrt is
+                                         v_sqrt_f32 - bit for bit what that build computes on this GPU.  Without the flag: the STRICT
+                                         arithmetic (every operation of the source correctly rounded, the build the same source gives
+                                         with -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt), also bit for bit.  Same cost. */
+
 /* What OpenCL_InitializeMemory copies with CL_MEM_COPY_HOST_PTR and passes as
  * kernel arguments 1..17 (OpenCL.cpp:165-197).  Arrays are raw dumps of the
  * ptmi_scene.h structs; a zero-length array may be NULL. */

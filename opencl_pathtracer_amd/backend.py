@@ -80,6 +80,9 @@ FLAG_NO_HISTOGRAMS = 1
 FLAG_SCHEDULER_STATS = 4  # collect scheduler_stats() (off by default)
 FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)
 FLAG_RUSSIAN_ROULETTE = 8  # non-parity mode: the reference's commented-out termination block (FullKernel.cl:1306-1314)
+# the arithmetic of the build the reference's own build line gives (OpenCL default: fused a*b+c, v_rcp_f32 division, v_sqrt_f32);
+# without it the strict arithmetic (-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt).  Both bit for bit.
+FLAG_DEFAULT_ARITHMETIC = 16
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",

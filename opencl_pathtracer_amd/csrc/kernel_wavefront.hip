@@ -50,7 +50,7 @@
 
 #include <cstring>
 
-namespace ptmi_dev {
+namespace PTMI_DEV_NS {
 
 constexpr int kWfBlock = 256;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         // an offset); after a closest-hit query the ray is the one that found the hit, and the point is
         // origin + direction * parameter evaluated as Triangle_Intersects does (FullKernel.cl:536).
         if (shadow) return r.o;
-        return r.o + (r.d * __uint_as_float(hit_mem[0 * kWfBlock]));
+        return mad(r.d, __uint_as_float(hit_mem[0 * kWfBlock]), r.o);
     };
     auto query_found = [&]() {
         return kHitWords == 8 ? (hit_mem[7 * kWfBlock] & 2u) != 0 : (hit_mem[kWordTri * kWfBlock] & kHitFound) != 0;
@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         if (sc.n_lights > 0) start_shadow = true;
                         else do_scatter = true;
                     } else {
-                        radiance = radiance + (sky_color(cold_scene().sky, sc.texels, r.d) * transfer);
+                        radiance = mad(sky_color(cold_scene().sky, sc.texels, r.d), transfer, radiance);  // cl:1287
                         end_path = missed = true;
                     }
                 } else {
@@ -688,14 +688,14 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                         ptmi_light light = sc.lights[kOneLight ? 0u : light_idx];
                         if (PLAIN) light.type = PTMI_LIGHT_POINT;
                         const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
-                        gathered = gathered + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
+                        gathered = mad(v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf), v4(light.color), gathered);  // cl:945
                         if (!kOneLight) direct = gathered;
                     }
                     if (do_scatter) {
                         r.d = cam_d;
                         V4 out;
                         radiance = radiance + scatter_direction(r, seed, in_water, sf, gathered, transfer, out);
-                        r.o = hit.point + out * 0.001f;  // :880 uses the un-normalised direction
+                        r.o = mad(out, 0.001f, hit.point);  // :880 uses the un-normalised direction
                         reflection++;
                         shadow = false;
                         if (!path_continues(transfer, reflection, seed, sc.russian_roulette != 0) || reflection >= sc.max_depth) {  // :1296-1314, :1248
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                 {
                     const DScene& cs = cold_scene();  // camera: only needed here, once per path
                     r.o = v4(cs.cam_pos);
-                    new_direction = (v4(cs.cam_dir) + (v4(cs.cam_right) * sample_x)) + (v4(cs.cam_up) * sample_y);
+                    new_direction = mad(v4(cs.cam_up), sample_y, mad(v4(cs.cam_right), sample_x, v4(cs.cam_dir)));  // cl:1213
                 }
                 radiance = v4(0, 0, 0, 0);
                 transfer = v4(1, 1, 1, 1);
@@ -791,10 +791,10 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
                     const uint32_t off = gy * sc.width + gx;
                     const float n = cs.image_ray_nb[off];
                     const float4 vv = reinterpret_cast<const float4*>(cs.image_v)[off];
-                    const float sigma2_n = fmaxf(fmaxf(vv.x / n, vv.y / n), vv.z / n);
+                    const float sigma2_n = fmaxf(fmaxf(fdiv(vv.x, n), fdiv(vv.y, n)), fdiv(vv.z, n));
                     uint32_t idx = (uint32_t)n;
                     if (idx > 1000u) idx = 1000u;  // the reference indexes past its 1001-entry table here
-                    skip = (double)lcg_random(seed) > (double)(100 * sigma2_n / cs.x2inv[idx]) + 0.05;
+                    skip = (double)lcg_random(seed) > (double)fdiv(100 * sigma2_n, cs.x2inv[idx]) + 0.05;
                 }
                 if (skip) {
                     cold_scene().stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
@@ -910,22 +910,53 @@ __global__ void __launch_bounds__(256) accumulate_staged_ss_kernel(float* __rest
     // a NaN variance for good; a first sample has no deviation, exactly like iteration 0.
     if (iteration != 0 && n_before != 0.f) {
         v = reinterpret_cast<const float4*>(image_v)[p];
-        v.x = v.x + (r.x - before.x / n_before) * (r.x - after.x / n_after);
-        v.y = v.y + (r.y - before.y / n_before) * (r.y - after.y / n_after);
-        v.z = v.z + (r.z - before.z / n_before) * (r.z - after.z / n_after);
-        v.w = v.w + (r.w - before.w / n_before) * (r.w - after.w / n_after);
+        v.x = mad(r.x - fdiv(before.x, n_before), r.x - fdiv(after.x, n_after), v.x);  // cl:1349
+        v.y = mad(r.y - fdiv(before.y, n_before), r.y - fdiv(after.y, n_after), v.y);
+        v.z = mad(r.z - fdiv(before.z, n_before), r.z - fdiv(after.z, n_after), v.z);
+        v.w = mad(r.w - fdiv(before.w, n_before), r.w - fdiv(after.w, n_after), v.w);
     }
     reinterpret_cast<float4*>(image_v)[p] = v;
 }
 
-}  // namespace ptmi_dev
+#if PTMI_DEFAULT_ARITHMETIC
+// The reciprocal determinant of a DTriPre record as the reference's default build computes it per test (FullKernel.cl:556:
+// fused uv*uv - uu*vv, then the reciprocal through v_rcp_f32): written once per upload, on the device because the
+// instruction's value is not reproducible on the host.  Node records (tri_ids == 0xFFFFFFFF) are left alone.
+__global__ void __launch_bounds__(256) precompute_denominators_kernel(DTri* __restrict__ records, const uint32_t* __restrict__ tri_ids,
+                                                                       const uint32_t n_records)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_records || tri_ids[i] == 0xFFFFFFFFu) return;
+    DTriPre* const p = reinterpret_cast<DTriPre*>(&records[i]);
+    const V4 u = v4(p->u_den[0], p->u_den[1], p->u_den[2], 0.0f), v = v4(p->v_s1w[0], p->v_s1w[1], p->v_s1w[2], 0.0f);
+    const float uv = dot(u, v), uu = dot(u, u), vv = dot(v, v);
+    p->u_den[3] = frcp(mad(uv, uv, -(uu * vv)));
+}
+#endif
+
+}  // namespace PTMI_DEV_NS
 
 namespace ptmi_internal {
+
+#if PTMI_DEFAULT_ARITHMETIC
+int launch_precompute_denominators_da(DTri* records, const uint32_t* tri_ids, uint32_t n_records, void* stream, std::string* err)
+{
+    if (n_records == 0) return PTMI_OK;
+    hipLaunchKernelGGL(PTMI_DEV_NS::precompute_denominators_kernel, dim3((n_records + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
+                       records, tri_ids, n_records);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("precompute_denominators_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    return PTMI_OK;
+}
+#endif
 
 static uint32_t clamp_levels(uint32_t stack_levels)
 {
     if (stack_levels < 1) stack_levels = 1;
-    if (stack_levels > (uint32_t)ptmi_dev::kWfStack) stack_levels = ptmi_dev::kWfStack;
+    if (stack_levels > (uint32_t)PTMI_DEV_NS::kWfStack) stack_levels = PTMI_DEV_NS::kWfStack;
     return stack_levels;
 }
 
@@ -933,22 +964,22 @@ static size_t wavefront_lds_bytes(uint32_t stack_levels)
 {
     stack_levels = clamp_levels(stack_levels);
     // closest-hit record + sentinel + stack (+ the keys and items of the leaf passes)
-    return ((size_t)(stack_levels + 1 + ptmi_dev::kHitWords) * ptmi_dev::kWfBlock + ptmi_dev::kLeafPassWords) * sizeof(uint32_t);
+    return ((size_t)(stack_levels + 1 + PTMI_DEV_NS::kHitWords) * PTMI_DEV_NS::kWfBlock + PTMI_DEV_NS::kLeafPassWords) * sizeof(uint32_t);
 }
 
-int wavefront_resident_blocks(int device, uint32_t stack_levels)
+int PTMI_ARITH(wavefront_resident_blocks)(int device, uint32_t stack_levels)
 {
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptmi_dev::render_wavefront_kernel<false, true, false>, ptmi_dev::kWfBlock,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PTMI_DEV_NS::render_wavefront_kernel<false, true, false>, PTMI_DEV_NS::kWfBlock,
                                                      wavefront_lds_bytes(stack_levels)) != hipSuccess)
         return 0;
     if (per_cu < 1) per_cu = 1;
     return per_cu * prop.multiProcessorCount;
 }
 
-int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
+int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
                             uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
                             bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err)
 {
@@ -960,15 +991,15 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
         return PTMI_ERR_INVALID_ARGUMENT;
     }
     const uint32_t n_jobs = (uint32_t)jobs64;
-    hipError_t e = hipMemsetAsync(job_counter, 0, ptmi_dev::kQueues * ptmi_dev::kQueueStride * sizeof(uint32_t), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(job_counter, 0, PTMI_DEV_NS::kQueues * PTMI_DEV_NS::kQueueStride * sizeof(uint32_t), (hipStream_t)stream);
     if (e == hipSuccess) {
-        uint32_t blocks = (n_jobs + ptmi_dev::kWfBlock - 1) / ptmi_dev::kWfBlock;
+        uint32_t blocks = (n_jobs + PTMI_DEV_NS::kWfBlock - 1) / PTMI_DEV_NS::kWfBlock;
         if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
-        const dim3 g(blocks), b(ptmi_dev::kWfBlock);
+        const dim3 g(blocks), b(PTMI_DEV_NS::kWfBlock);
         const size_t lds = wavefront_lds_bytes(stack_levels);
         const uint32_t lv = clamp_levels(stack_levels);
         hipStream_t st = (hipStream_t)stream;
-        ptmi_dev::DWarm warm{};
+        PTMI_DEV_NS::DWarm warm{};
         warm.nodes = sc.nodes; warm.tris = sc.tris; warm.big_leaves = sc.big_leaves; warm.tri_ids = sc.tri_ids; warm.shade = sc.shade;
         warm.mats = sc.mats; warm.lights = sc.lights; warm.textures = sc.textures; warm.texels = sc.texels;
         warm.root_ref = sc.root_ref; warm.width = sc.width; warm.height = sc.height; warm.max_depth = sc.max_depth;
@@ -981,7 +1012,7 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
                            sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats;
         warm.wait_debt = lv >= 16u ? 768u : (plain ? 320u : 512u);  // (the cheaper a path-logic pass, the sooner it pays)
 #define PTMI_LAUNCH_WF_IMPL(S, P, A, L)                                                                              \
-    hipLaunchKernelGGL((ptmi_dev::render_wavefront_kernel<S, P, A, L>), g, b, lds, st, scene_in_device_memory, warm, \
+    hipLaunchKernelGGL((PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L>), g, b, lds, st, scene_in_device_memory, warm, \
                        first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)
 #define PTMI_LAUNCH_WF(S, P, A)                                                                                       \
     PTMI_LAUNCH_WF_IMPL(S, P, A, false)
@@ -1009,33 +1040,33 @@ int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memo
 // What follows a wavefront launch of a sampler that owns its pixels: the staged radiances into the accumulators (per pixel,
 // in iteration order) and the staged statistics words into the three histograms.  May run on another stream than the
 // launch (the caller orders them with an event): these two small kernels are what keeps launches in iteration order.
-int launch_accumulate_staged(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,
+int PTMI_ARITH(launch_accumulate_staged)(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,
                              const uint32_t* stage_stats, bool with_histograms, void* stream, std::string* err)
 {
     if (n_iterations == 0 || sc.sampler == PTMI_SAMPLER_RANDOM) return PTMI_OK;
     const uint32_t n_pixels = sc.width * sc.height;
     if (sc.super_sampling)
-        hipLaunchKernelGGL(ptmi_dev::accumulate_staged_ss_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+        hipLaunchKernelGGL(PTMI_DEV_NS::accumulate_staged_ss_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
                            (hipStream_t)stream, sc.image_color, sc.image_ray_nb, sc.image_v, stage, sc.stage_flag, n_pixels, first_iteration);
     else
-        hipLaunchKernelGGL(ptmi_dev::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
+        hipLaunchKernelGGL(PTMI_DEV_NS::accumulate_staged_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0,
                            (hipStream_t)stream, sc.image_color, sc.image_ray_nb, stage, n_pixels, n_iterations);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("accumulate_staged_kernel launch: ") + hipGetErrorString(e);
         return PTMI_ERR_HIP;
     }
-    if (with_histograms && stage_stats != nullptr) return launch_histogram_staged(sc, n_iterations, stage_stats, stream, err);
+    if (with_histograms && stage_stats != nullptr) return PTMI_ARITH(launch_histogram_staged)(sc, n_iterations, stage_stats, stream, err);
     return PTMI_OK;
 }
 
 // the staged statistics words of `n_iterations` iterations into the three histograms
-int launch_histogram_staged(const DScene& sc, uint32_t n_iterations, const uint32_t* stage_stats, void* stream, std::string* err)
+int PTMI_ARITH(launch_histogram_staged)(const DScene& sc, uint32_t n_iterations, const uint32_t* stage_stats, void* stream, std::string* err)
 {
     const uint32_t n_slots = sc.width * sc.height * n_iterations;
     uint32_t hb = (n_slots + 1023u) / 1024u;
     if (hb > 512u) hb = 512u;
-    hipLaunchKernelGGL(ptmi_dev::histogram_staged_kernel, dim3(hb), dim3(1024), 0, (hipStream_t)stream, sc.hist_depths,
+    hipLaunchKernelGGL(PTMI_DEV_NS::histogram_staged_kernel, dim3(hb), dim3(1024), 0, (hipStream_t)stream, sc.hist_depths,
                        sc.hist_bbx, sc.hist_tri, stage_stats, sc.super_sampling ? sc.stage_flag : nullptr, n_slots);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -18,7 +18,7 @@
 #include "ptmi_device.hpp"
 #include "ptmi_shading.hpp"
 
-namespace ptmi_dev {
+namespace PTMI_DEV_NS {
 
 constexpr int kBlock = 256;
 constexpr int kStackDepth = PTMI_BVH_MAX_DEPTH;
@@ -99,7 +99,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
 
     Ray r;
     r.o = v4(sc.cam_pos);
-    ray_set_direction(r, (v4(sc.cam_dir) + (v4(sc.cam_right) * sample_x)) + (v4(sc.cam_up) * sample_y));
+    ray_set_direction(r, mad(v4(sc.cam_up), sample_y, mad(v4(sc.cam_right), sample_x, v4(sc.cam_dir))));  // cl:1213
 
     V4 radiance = v4(0, 0, 0, 0), transfer = v4(1, 1, 1, 1);
     bool active = true, in_water = false;
@@ -129,14 +129,14 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
                 Hit dummy;
                 shadows++;
                 if (!traverse<true, PRE>(sc, lr, light_distance, dummy, pc, stack))
-                    direct = direct + (v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf)) * v4(light.color);
+                    direct = mad(v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf), v4(light.color), direct);  // cl:945
             }
 
             radiance = radiance + scatter(r, seed, in_water, hit, sf, direct, transfer);
             reflection++;
         } else {
             active = false;
-            radiance = radiance + (sky_color(sc.sky, sc.texels, r.d) * transfer);  // :1281-1288
+            radiance = mad(sky_color(sc.sky, sc.texels, r.d), transfer, radiance);  // :1281-1288
         }
         if (active) active = path_continues(transfer, reflection, seed, sc.russian_roulette != 0);  // :1296-1314
     }
@@ -216,20 +216,20 @@ __global__ void __launch_bounds__(kBlock) render_kernel(const DScene sc, const u
     if (tid <= C_TRI) atomicAdd(&sc.counters[tid], block_counters[tid]);
 }
 
-}  // namespace ptmi_dev
+}  // namespace PTMI_DEV_NS
 
 namespace ptmi_internal {
 
-int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t iteration_stride, void* stream,
+int PTMI_ARITH(launch_render)(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t iteration_stride, void* stream,
                   std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
     const dim3 grid((sc.width + 15u) / 16u, (sc.height + 15u) / 16u);
     if (sc.tris_precomputed)
-        hipLaunchKernelGGL(ptmi_dev::render_kernel<true>, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
+        hipLaunchKernelGGL(PTMI_DEV_NS::render_kernel<true>, grid, dim3(PTMI_DEV_NS::kBlock), 0, (hipStream_t)stream, sc,
                            first_iteration, n_iterations, iteration_stride);
     else
-        hipLaunchKernelGGL(ptmi_dev::render_kernel<false>, grid, dim3(ptmi_dev::kBlock), 0, (hipStream_t)stream, sc,
+        hipLaunchKernelGGL(PTMI_DEV_NS::render_kernel<false>, grid, dim3(PTMI_DEV_NS::kBlock), 0, (hipStream_t)stream, sc,
                            first_iteration, n_iterations, iteration_stride);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

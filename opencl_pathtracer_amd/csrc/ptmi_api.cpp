@@ -100,6 +100,10 @@ struct ptmi_ctx {
 
 namespace {
 
+// the integrator's entry points in the context's arithmetic mode (ptmi_internal.h)
+bool default_arithmetic(const ptmi_ctx* ctx) { return (ctx->cfg.flags & PTMI_FLAG_DEFAULT_ARITHMETIC) != 0; }
+#define KERNELS_OF(ctx, name) (default_arithmetic(ctx) ? name##_da : name)
+
 int fail(ptmi_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->err = msg;
@@ -420,6 +424,13 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     ds.n_records = (uint32_t)lay.recs.size();
     ds.wide_records = (lay.recs.size() > (1u << 26) || std::getenv("PTMI_WIDE_RECORDS") != nullptr) ? 1u : 0u;  // env: test switch
     if (int rc = upload(ctx, d, lay.tri_ids, &ds.tri_ids)) return rc;
+    if (default_arithmetic(ctx) && lay.tris_precomputed) {
+        // the records' reciprocal determinants in the reference's default arithmetic: a device instruction's values
+        std::string err;
+        if (int rc = launch_precompute_denominators_da(const_cast<DTri*>(ds.tris), ds.tri_ids, ds.n_records, d.stream, &err))
+            return fail(ctx, rc, err);
+        HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    }
     if (int rc = upload(ctx, d, lay.shade, &ds.shade)) return rc;
     if (int rc = upload(ctx, d, lay.mats, &ds.mats)) return rc;
     if (int rc = upload(ctx, d, lay.big_leaves, &ds.big_leaves)) return rc;
@@ -462,7 +473,7 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
     std::memcpy(ds.cam_right, &sc->camera_right, 16);
     std::memcpy(ds.cam_up, &sc->camera_up, 16);
-    d.resident_blocks = wavefront_resident_blocks(d.device, ctx->stack_levels);
+    d.resident_blocks = KERNELS_OF(ctx, wavefront_resident_blocks)(d.device, ctx->stack_levels);
     ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
     ds.plain_shading = lay.plain_shading ? 1u : 0u;
     ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
@@ -580,7 +591,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     hipError_t e = hipEventRecord(ev.first, d.stream);
     if (e == hipSuccess) {
         if (megakernel) {
-            rc = launch_render(d.ds, first, n, stride, d.stream, &err);
+            rc = KERNELS_OF(ctx, launch_render)(d.ds, first, n, stride, d.stream, &err);
         } else {
             // one launch per chunk of iterations
             for (uint32_t done = 0; done < n && rc == PTMI_OK && e == hipSuccess;) {
@@ -601,7 +612,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + d.stage_iterations * npix * 16);
                 if (may_overlap && d.stage_busy[set]) e = hipStreamWaitEvent(ls, d.stage_free[set], 0);
                 if (e != hipSuccess) break;
-                rc = launch_render_wavefront(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter + set * 8 * 1024,
+                rc = KERNELS_OF(ctx, launch_render_wavefront)(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter + set * 8 * 1024,
                                              d.resident_blocks, ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, stage,
                                              stage_stats, ls, &err);
                 if (rc != PTMI_OK) break;
@@ -611,19 +622,19 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     if (e != hipSuccess) break;
                 }
                 if (!plan) {
-                    rc = launch_accumulate_staged(d.ds, first + done * stride, m, stage, stage_stats, true, d.stream, &err);
+                    rc = KERNELS_OF(ctx, launch_accumulate_staged)(d.ds, first + done * stride, m, stage, stage_stats, true, d.stream, &err);
                 } else {
                     // one accumulation per iteration, each followed by the snapshots of the global iterations up to it
                     for (uint32_t j = 0; j < m && rc == PTMI_OK; j++) {
                         const uint32_t id = first + (done + j) * stride;
                         rc = snapshots_up_to(ctx, d, *plan, id - plan->first);  // images before this device's next own one
                         if (rc != PTMI_OK) break;
-                        rc = launch_accumulate_staged(d.ds, id, 1, stage + (size_t)j * npix * 4, stage_stats ? stage_stats + (size_t)j * npix : nullptr,
-                                                      false, d.stream, &err);
+                        rc = KERNELS_OF(ctx, launch_accumulate_staged)(d.ds, id, 1, stage + (size_t)j * npix * 4,
+                                                                       stage_stats ? stage_stats + (size_t)j * npix : nullptr, false, d.stream, &err);
                         if (rc == PTMI_OK) rc = snapshots_up_to(ctx, d, *plan, id - plan->first + 1);
                     }
                     if (rc == PTMI_OK && stage_stats)
-                        rc = launch_histogram_staged(d.ds, m, stage_stats, d.stream, &err);
+                        rc = KERNELS_OF(ctx, launch_histogram_staged)(d.ds, m, stage_stats, d.stream, &err);
                     if (rc != PTMI_OK && err.empty()) err = ctx->err;
                 }
                 if (rc != PTMI_OK) break;

@@ -14,9 +14,37 @@
 #include "ptmi_detmath.h"
 #include "ptmi_internal.h"
 
-namespace ptmi_dev {
+// ---- the two arithmetic modes ---------------------------------------------------------------------------
+// The reference compiles its kernel at run time with no floating-point option (PathTracer_OpenCL.cpp:292-314), so what it
+// computes is its OpenCL compiler's DEFAULT arithmetic; with -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt the
+// same source gives the STRICT arithmetic.  Both are restated here bit for bit; the device sources are compiled once per
+// mode (Makefile) into two namespaces, and a context picks one (PTMI_FLAG_DEFAULT_ARITHMETIC).
+//   strict  (PTMI_DEFAULT_ARITHMETIC 0): every + - * / sqrt of the source is one correctly rounded operation.
+//   default (PTMI_DEFAULT_ARITHMETIC 1): what clang's OpenCL front end and the gfx950 back end make of the same source:
+//     * `a * b + c` written inside ONE expression (also `x += a * b`) is one fused multiply-add (-ffp-contract=on is a
+//       source-level rule: llvm.fmuladd where the multiplication is a direct operand of the addition; the left operand is
+//       tried first).  Each such site below is a mad() and cites the reference line;
+//     * a / b   = ldexp(frexp_mant(a) * v_rcp_f32(frexp_mant(b)), frexp_exp(a) - frexp_exp(b))  (the 2.5-ulp division of
+//       AMDGPUCodeGenPrepare with denormals enabled); with a CONSTANT divisor the reciprocal of its mantissa is folded at
+//       compile time, i.e. correctly rounded instead of the instruction's value: fdiv(a, DivC);
+//     * sqrt(x) = v_sqrt_f32 behind a 2^32 scaling of denormal inputs.
+//   The platform library (dot, cross, normalize, length's range scaling, sin, cos) is the same code in both modes.
+#ifndef PTMI_DEFAULT_ARITHMETIC
+#define PTMI_DEFAULT_ARITHMETIC 0
+#endif
+#if PTMI_DEFAULT_ARITHMETIC
+#define PTMI_DEV_NS ptmi_dev_da
+#define PTMI_ARITH(name) name##_da
+#else
+#define PTMI_DEV_NS ptmi_dev
+#define PTMI_ARITH(name) name
+#endif
+
+namespace PTMI_DEV_NS {
 
 using namespace ptmi_internal;
+
+constexpr bool kDefaultArithmetic = PTMI_DEFAULT_ARITHMETIC != 0;
 
 struct V4 {
     float x, y, z, w;
@@ -33,6 +61,52 @@ __device__ __forceinline__ V4 operator*(V4 a, float s) { return V4{a.x * s, a.y 
 __device__ __forceinline__ V4 operator/(V4 a, float s) { return V4{a.x / s, a.y / s, a.z / s, a.w / s}; }
 __device__ __forceinline__ V4 operator-(V4 a) { return V4{-a.x, -a.y, -a.z, -a.w}; }
 
+// a * b + c where the reference writes it in one expression: two roundings (strict) or one (default)
+__device__ __forceinline__ float mad(float a, float b, float c)
+{
+    if (kDefaultArithmetic) return __builtin_fmaf(a, b, c);
+    return a * b + c;
+}
+__device__ __forceinline__ V4 mad(V4 a, V4 b, V4 c) { return V4{mad(a.x, b.x, c.x), mad(a.y, b.y, c.y), mad(a.z, b.z, c.z), mad(a.w, b.w, c.w)}; }
+__device__ __forceinline__ V4 mad(V4 a, float s, V4 c) { return V4{mad(a.x, s, c.x), mad(a.y, s, c.y), mad(a.z, s, c.z), mad(a.w, s, c.w)}; }
+// a / b, b a run-time value
+__device__ __forceinline__ float fdiv(float a, float b)
+{
+    if (!kDefaultArithmetic) return a / b;
+    return __builtin_ldexpf(__builtin_amdgcn_frexp_mantf(a) * __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(b)),
+                            __builtin_amdgcn_frexp_expf(a) - __builtin_amdgcn_frexp_expf(b));
+}
+// 1.0f / b (the compiler's form for a numerator of one: the same value as fdiv(1, b), two instructions fewer)
+__device__ __forceinline__ float frcp(float b)
+{
+    if (!kDefaultArithmetic) return 1.0f / b;
+    return __builtin_ldexpf(__builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(b)), -__builtin_amdgcn_frexp_expf(b));
+}
+// a / c, c a constant of the reference's program (a literal, or IMAGE_WIDTH / IMAGE_HEIGHT which it bakes in with -D):
+// c = m * 2^e, m in [0.5, 1); inv_mant = 1 / m correctly rounded
+struct DivC {
+    float c, inv_mant;
+    int exp;
+};
+constexpr DivC make_divc(float c)  // (c positive and normal)
+{
+    const uint32_t bits = __builtin_bit_cast(uint32_t, c);
+    const float m = __builtin_bit_cast(float, (bits & 0x007FFFFFu) | 0x3F000000u);
+    return DivC{c, 1.0f / m, (int)((bits >> 23) & 0xFFu) - 126};
+}
+__device__ __forceinline__ float fdiv(float a, const DivC& d)
+{
+    if (!kDefaultArithmetic) return a / d.c;
+    return __builtin_ldexpf(__builtin_amdgcn_frexp_mantf(a) * d.inv_mant, __builtin_amdgcn_frexp_expf(a) - d.exp);
+}
+__device__ __forceinline__ float fsqrt(float x)
+{
+    if (!kDefaultArithmetic) return sqrtf(x);
+    const bool tiny = x < 0x1p-126f;
+    const float r = __builtin_amdgcn_sqrtf(tiny ? __builtin_ldexpf(x, 32) : x);
+    return tiny ? __builtin_ldexpf(r, -16) : r;
+}
+
 // The OpenCL geometric builtins, fixed to the definitions of the OpenCL library the reference meets on
 // this hardware (ROCm device libs, opencl.bc): dot and cross are its FMA chains verbatim, normalize below.
 // DESIGN.md "Numerics".
@@ -40,7 +114,23 @@ __device__ __forceinline__ float dot(V4 a, V4 b)
 {
     return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
 }
-__device__ __forceinline__ float length(V4 a) { return sqrtf(dot(a, a)); }
+// length(float4) of the library (_Z6lengthDv4_f): sqrt(dot) with a rescaling for squared lengths outside the normal range
+// (never taken by a light distance in the strict mode's tests, where the branches only matter for overflow; kept literally
+// in the default mode, whose square root is the instruction)
+__device__ __forceinline__ float length(V4 a)
+{
+    const float d = dot(a, a);
+    if (!kDefaultArithmetic) return sqrtf(d);
+    if (d < 0x1p-126f) {
+        a = a * 0x1p+86f;
+        return fsqrt(dot(a, a)) * 0x1p-86f;
+    }
+    if (d == INFINITY) {
+        a = a * 0x1p-66f;
+        return fsqrt(dot(a, a)) * 0x1p+66f;
+    }
+    return __builtin_amdgcn_sqrtf(d);
+}
 // normalize(float4) of the ROCm OpenCL library (opencl.bc, _Z9normalizeDv4_f): the vector times rsqrt(dot), where rsqrt is
 // __ocml_rsqrt_f32 = the hardware's v_rsq_f32 (one ulp off the correctly rounded value for 11 % of the inputs) behind range
 // scaling for tiny / infinite squared lengths; the zero vector is returned as it is.  Written out in full so that the
@@ -90,9 +180,9 @@ struct Ray {
 __device__ __forceinline__ void ray_set_direction(Ray& r, V4 d)
 {
     r.d = normalize(d);
-    r.ix = 1.0f / r.d.x;
-    r.iy = 1.0f / r.d.y;
-    r.iz = 1.0f / r.d.z;
+    r.ix = frcp(r.d.x);
+    r.iy = frcp(r.d.y);
+    r.iz = frcp(r.d.z);
 }
 
 // random(), header.cl:246-253.  Only the low 31 bits of the 64-bit product
@@ -118,7 +208,7 @@ __device__ __forceinline__ int lcg_seed(uint32_t gx, uint32_t gy, uint32_t w, ui
 __device__ __forceinline__ V4 put_in_same_hemisphere(V4 v, V4 n)
 {
     const float d = dot(v, n);
-    if (d < 0.001f) v = v + n * (0.01f - d);
+    if (d < 0.001f) v = mad(n, 0.01f - d, v);  // h:241 `(*This) += (*N) * (0.01f - dotProd)`
     return v;
 }
 
@@ -200,16 +290,16 @@ __device__ __forceinline__ bool tri_hit(const V4 S1, const V4 S2, const V4 S3, c
     const float d = dot(N, S1);
     const float nd = dot(N, r.d);
     if ((nd > -0.00001f) && (nd < 0.00001f)) return false;
-    const V4 q = r.o + (r.d * ((d - dot(N, r.o)) / nd));
+    const V4 q = mad(r.d, fdiv(d - dot(N, r.o), nd), r.o);  // cl:538
     const V4 full = q - r.o;
     const float nsd = dot(full, full);
     if (nsd > limit) return false;
     if (nsd < 0.00001f) return false;
     const V4 w = q - S1;
     const float uv = dot(u, v), wv = dot(w, v), wu = dot(w, u), uu = dot(u, u), vv = dot(v, v);
-    const float denom = 1 / (uv * uv - uu * vv);
-    const float s = (uv * wv - vv * wu) * denom;
-    const float t = (uv * wu - uu * wv) * denom;
+    const float denom = frcp(mad(uv, uv, -(uu * vv)));  // cl:556
+    const float s = mad(uv, wv, -(vv * wu)) * denom;    // cl:558
+    const float t = mad(uv, wu, -(uu * wv)) * denom;    // cl:559
     if (s < 0 || t < 0 || s + t > 1) return false;
     if (dot(full, r.d) < 0) return false;
     limit = nsd;
@@ -232,7 +322,7 @@ __device__ __forceinline__ bool tri_hit_pre(const V4 N, const V4 s1d, const V4 u
     const float d = s1d.w;
     const float nd = dot(N, r.d);
     if ((nd > -0.00001f) && (nd < 0.00001f)) return false;
-    const V4 q = r.o + (r.d * ((d - dot(N, r.o)) / nd));
+    const V4 q = mad(r.d, fdiv(d - dot(N, r.o), nd), r.o);  // cl:538
     const V4 full = q - r.o;
     const float nsd = dot(full, full);
     if (nsd > limit) return false;
@@ -240,8 +330,8 @@ __device__ __forceinline__ bool tri_hit_pre(const V4 N, const V4 s1d, const V4 u
     const V4 w = q - S1;
     const float uv = dot(u, v), wv = dot(w, v), wu = dot(w, u), uu = dot(u, u), vv = dot(v, v);
     const float denom = u_den.w;
-    const float s = (uv * wv - vv * wu) * denom;
-    const float t = (uv * wu - uu * wv) * denom;
+    const float s = mad(uv, wv, -(vv * wu)) * denom;  // cl:558
+    const float t = mad(uv, wu, -(uu * wv)) * denom;  // cl:559
     if (s < 0 || t < 0 || s + t > 1) return false;
     if (dot(full, r.d) < 0) return false;
     limit = nsd;
@@ -295,8 +385,9 @@ __device__ __forceinline__ void tri_test(const float4 e0, const float4 e1, LateQ
     const V4 N = PRE ? v4(e0) : v4(e1);
     const float d = PRE ? e1.w : dot(v4(e1), v4(e0));
     const float nd = dot(N, r.d);
-    const float ray_t = div_unscaled(d - dot(N, r.o), nd);  // (d - N.o) / nd; measured +0.6 % over the compiler's expansion
-    const V4 q = r.o + (r.d * ray_t);
+    // (d - N.o) / nd.  strict: measured +0.6 % over the compiler's expansion; default: the reference's own 2.5-ulp form
+    const float ray_t = kDefaultArithmetic ? fdiv(d - dot(N, r.o), nd) : div_unscaled(d - dot(N, r.o), nd);
+    const V4 q = mad(r.d, ray_t, r.o);  // cl:538
     const V4 full = q - r.o;
     const float nsd = dot(full, full);
     const float fd = dot(full, r.d);
@@ -316,9 +407,9 @@ __device__ __forceinline__ void tri_test(const float4 e0, const float4 e1, LateQ
         }
         const V4 w = q - S1;
         const float uv = dot(u, v), wv = dot(w, v), wu = dot(w, u), uu = dot(u, u), vv = dot(v, v);
-        const float denom = PRE ? l0.w : 1 / (uv * uv - uu * vv);
-        const float s = (uv * wv - vv * wu) * denom;
-        const float t = (uv * wu - uu * wv) * denom;
+        const float denom = PRE ? l0.w : frcp(mad(uv, uv, -(uu * vv)));  // cl:556
+        const float s = mad(uv, wv, -(vv * wu)) * denom;                   // cl:558
+        const float t = mad(uv, wu, -(uu * wv)) * denom;                   // cl:559
         if (!((s < 0) | (t < 0) | (s + t > 1))) on_accept(q, ray_t, s, t, nd < 0, nsd);
     }
 }
@@ -337,7 +428,8 @@ __device__ __forceinline__ V4 texture_pixel(const ptmi_texture& tex, const ptmi_
     const uint32_t x = (uint32_t)(u * (float)(tex.width - 1u));
     const uint32_t y = (uint32_t)(v * (float)(tex.height - 1u));
     const ptmi_uchar4 p = texels[tex.offset + y * tex.width + x];
-    V4 c = V4{(float)p.x / 255.f, (float)p.y / 255.f, (float)p.z / 255.f, (float)p.w / 255.f};
+    constexpr DivC k255 = make_divc(255.f);
+    V4 c = V4{fdiv((float)p.x, k255), fdiv((float)p.y, k255), fdiv((float)p.z, k255), fdiv((float)p.w, k255)};
     c.w = 1.f - c.w;
     return c;
 }
@@ -345,46 +437,53 @@ __device__ __forceinline__ V4 texture_pixel(const ptmi_texture& tex, const ptmi_
 // Sky_GetColorValue + Sky_GetFaceColorValue, FullKernel.cl:438-512
 __device__ __forceinline__ V4 sky_color(const ptmi_sky& sky, const ptmi_uchar4* __restrict__ texels, V4 d)
 {
-    const float x = sky.cos_rotation_angle * d.x - sky.sin_rotation_angle * d.y;
-    const float y = sky.sin_rotation_angle * d.x + sky.cos_rotation_angle * d.y;
+    const float x = mad(sky.cos_rotation_angle, d.x, -(sky.sin_rotation_angle * d.y));  // cl:441
+    const float y = mad(sky.sin_rotation_angle, d.x, sky.cos_rotation_angle * d.y);     // cl:442
     const float z = d.z;
     const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
     int face = 0;
     float u = 0, v = 0;
     if (az > ax && az > ay) {
-        if (z > 0) { face = 5; u = (1 - x / z) / 2; v = (1 + y / z) / 2; }
-        else       { face = 0; u = (1 + x / z) / 2; v = (1 + y / z) / 2; }
+        if (z > 0) { face = 5; u = (1 - fdiv(x, z)) / 2; v = (1 + fdiv(y, z)) / 2; }
+        else       { face = 0; u = (1 + fdiv(x, z)) / 2; v = (1 + fdiv(y, z)) / 2; }
     } else if (ax > ay && ax > az) {
-        if (x > 0) { face = 1; u = (1 - y / x) / 2; v = (1 + z / x) / 2; }
-        else       { face = 3; u = (1 - y / x) / 2; v = (1 - z / x) / 2; }
+        if (x > 0) { face = 1; u = (1 - fdiv(y, x)) / 2; v = (1 + fdiv(z, x)) / 2; }
+        else       { face = 3; u = (1 - fdiv(y, x)) / 2; v = (1 - fdiv(z, x)) / 2; }
     } else if (ay > ax && ay > az) {
-        if (y > 0) { face = 4; u = (1 + x / y) / 2; v = (1 + z / y) / 2; }
-        else       { face = 2; u = (1 + x / y) / 2; v = (1 - z / y) / 2; }
+        if (y > 0) { face = 4; u = (1 + fdiv(x, y)) / 2; v = (1 + fdiv(z, y)) / 2; }
+        else       { face = 2; u = (1 + fdiv(x, y)) / 2; v = (1 - fdiv(z, y)) / 2; }
     }
     return texture_pixel(sky.sky_textures[face], texels, u, v);
 }
 
 // Fresnel core shared by FullKernel.cl:192-217 (glass), :219-254 (water), :256-292 (varnish)
-__device__ __forceinline__ float fresnel_fraction(float n1, float n2, float cos1, V4 incident, V4 N, V4* refr)
+// `n2` is a run-time value in the water function (selected by isInWater, cl:223-232) and a literal in the glass and varnish
+// functions: the default arithmetic divides differently by the two (see fdiv), hence the divisor type.
+template <class Divisor>
+__device__ __forceinline__ float fresnel_fraction(float n1, float n2, const Divisor& by_n2, float cos1, V4 incident, V4 N, V4* refr)
 {
-    const float sin1 = sqrtf(1 - cos1 * cos1);
-    const float sin2 = n1 * sin1 / n2;
+    const float sin1 = fsqrt(mad(-cos1, cos1, 1));  // cl:202,235,275 `1 - cos1 * cos1`
+    const float sin2 = fdiv(n1 * sin1, by_n2);
     if (sin2 >= 1) return 1;
-    const float cos2 = sqrtf(1 - sin2 * sin2);
-    const float r_para = (n2 * cos1 - n1 * cos2) / (n2 * cos1 + n1 * cos2);
-    const float r_perp = (n1 * cos1 - n2 * cos2) / (n1 * cos1 + n2 * cos2);
-    if (refr) *refr = incident * (n1 / n2) + N * (n1 / n2 * cos1 - cos2);
-    return (r_para * r_para + r_perp * r_perp) / 2.0f;
+    const float cos2 = fsqrt(mad(-sin2, sin2, 1));
+    const float r_para = fdiv(mad(n2, cos1, -(n1 * cos2)), mad(n2, cos1, n1 * cos2));  // cl:208
+    const float r_perp = fdiv(mad(n1, cos1, -(n2 * cos2)), mad(n1, cos1, n2 * cos2));  // cl:209
+    if (refr) {  // cl:249 (water only: a run-time n1 / n2)
+        const float ratio = fdiv(n1, n2);
+        *refr = mad(incident, ratio, N * mad(ratio, cos1, -cos2));
+    }
+    return mad(r_para, r_para, r_perp * r_perp) / 2.0f;  // cl:211
 }
 
 __device__ __forceinline__ float fresnel_varnish(V4 incident, V4 N)
 {
     const float cos1 = fmaxf(0.f, fminf(1.f, -dot(incident, N)));
-    return fresnel_fraction(1.0f, kNVarnish, cos1, incident, N, nullptr);
+    constexpr DivC by_n2 = make_divc(kNVarnish);
+    return fresnel_fraction(1.0f, kNVarnish, by_n2, cos1, incident, N, nullptr);
 }
 
 // Material_FresnelReflection, FullKernel.cl:294-300
-__device__ __forceinline__ V4 reflect_about(V4 v, V4 N) { return v - (N * (2 * dot(v, N))); }
+__device__ __forceinline__ V4 reflect_about(V4 v, V4 N) { return mad(-N, 2 * dot(v, N), v); }  // cl:298
 
 // Material_BRDF, FullKernel.cl:166-190
 __device__ __forceinline__ float material_brdf(int type, V4 incident, V4 N, V4 reflected)
@@ -392,8 +491,8 @@ __device__ __forceinline__ float material_brdf(int type, V4 incident, V4 N, V4 r
     if (type == PTMI_MAT_STANDART) return kPiInverse;
     if (type == PTMI_MAT_GLASS) return 1;
     if (type == PTMI_MAT_WATER) {
-        const float denom = 1 + kSchlick * dot(incident, reflected);
-        return (1 - kSchlick * kSchlick) / (4 * kPi * denom * denom);
+        const float denom = mad(kSchlick, dot(incident, reflected), 1);  // cl:177
+        return fdiv(1 - kSchlick * kSchlick, 4 * kPi * denom * denom);
     }
     if (type == PTMI_MAT_VARNHISHED) return (1 - fresnel_varnish(incident, N)) * kPiInverse;
     return 1;
@@ -404,8 +503,8 @@ __device__ __forceinline__ V4 cosine_sample_hemisphere(int& seed, V4 N)
 {
     const float u1 = lcg_random(seed);
     const float u2 = lcg_random(seed);
-    const float sx = 2 * u1 - 1;
-    const float sy = 2 * u2 - 1;
+    const float sx = mad(2, u1, -1);  // cl:350
+    const float sy = mad(2, u2, -1);
     // The reference's four octant pairs (:356-397), each with a division of its own:
     //   sx > -sy:  sx > sy ? (r = sx, theta = sy > 0 ? sy/sx : 8 + sy/sx) : (r = sy, theta = 2 - sx/sy)
     //   else:      sx < sy ? (r = -sx, theta = 4 + sy/sx)                 : (r = -sy, theta = 6 - sy/sx)
@@ -413,7 +512,7 @@ __device__ __forceinline__ V4 cosine_sample_hemisphere(int& seed, V4 N)
     // branchy form executes every copy of the ~10-instruction division): same operations per lane, same bits.
     const bool upper = sx > -sy;
     const bool pair_a = upper & (sx > sy), pair_b = upper & !(sx > sy), pair_c = !upper & (sx < sy);
-    const float q = (pair_b ? sx : sy) / (pair_b ? sy : sx);
+    const float q = fdiv(pair_b ? sx : sy, pair_b ? sy : sx);
     float r = pair_a ? sx : (pair_b ? sy : (pair_c ? -sx : -sy));
     float theta = pair_a ? (sy > 0 ? q : 8.f + q) : (pair_b ? 2.f - q : (pair_c ? 4.f + q : 6.f - q));
     if (fabsf(sy) < 0.0001f) { r = sx; theta = 2; }
@@ -423,7 +522,10 @@ __device__ __forceinline__ V4 cosine_sample_hemisphere(int& seed, V4 N)
     float sn, cs;
     ptmi_sincosf(theta, &sn, &cs);
     const float x = r * cs, y = r * sn;
-    float z = 1 - x * x - y * y;
+    float z = mad(-y, y, mad(-x, x, 1));  // cl:311 `1 - x*x - y*y`
+    // This square root is CORRECTLY ROUNDED in both arithmetics: `z = (z<0) ? 0 : sqrt(z)` (cl:312) becomes a select, and the
+    // call the optimizer speculates for it loses the !fpmath annotation that lets every other sqrt of the default build be
+    // v_sqrt_f32 (the optimized IR of the reference kernel shows llvm.sqrt without it exactly here).
     z = (z < 0) ? 0 : sqrtf(z);
     const V4 v = v4(x, y, z, 0);
     if (N.z > 0.9999f) return v;
@@ -441,16 +543,16 @@ __device__ __forceinline__ float light_power_toward(const ptmi_light& l, V4 p, V
     if (l.type == PTMI_LIGHT_DIRECTIONNAL) return l.power * fmaxf(dot(-dir, N), 0.f);
     if (l.type == PTMI_LIGHT_POINT) {
         const V4 d = p - pos;
-        return l.power / dot(d, d) * fmaxf(dot(normalize(pos - p), N), 0.f);
+        return fdiv(l.power, dot(d, d)) * fmaxf(dot(normalize(pos - p), N), 0.f);
     }
     if (l.type == PTMI_LIGHT_SPOT) {
         const V4 lrd = normalize(p - pos);
         const float cos_angle = dot(lrd, dir);
         if (cos_angle > l.cos_inner) return l.power * fmaxf(-dot(lrd, N), 0.f);
         if (cos_angle < l.cos_outer) return 0.0f;
-        return l.power * (cos_angle - l.cos_outer) / (l.cos_inner - l.cos_outer) * fmaxf(-dot(lrd, N), 0.f);
+        return fdiv(l.power * (cos_angle - l.cos_outer), l.cos_inner - l.cos_outer) * fmaxf(-dot(lrd, N), 0.f);
     }
     return 0.f;
 }
 
-}  // namespace ptmi_dev
+}  // namespace PTMI_DEV_NS

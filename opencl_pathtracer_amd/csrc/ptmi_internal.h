@@ -135,23 +135,35 @@ struct DScene {
     uint32_t russian_roulette; // PTMI_FLAG_RUSSIAN_ROULETTE
 };
 
-// kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)
-// iteration ids of a launch: first_iteration + k * iteration_stride, k < n_iterations
-int launch_render(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t iteration_stride, void* stream,
-                  std::string* err);
-
-// kernel_wavefront.hip: persistent wavefront state machine (default)
-// stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30)
-int wavefront_resident_blocks(int device, uint32_t stack_levels);
-// scene_in_device_memory = a device copy of `sc` (the kernel takes only the hot fields by value)
-int launch_render_wavefront(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
-                            uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
-                            bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err);
-// stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself)
-// ... and what must follow it, in launch order: staged radiances -> accumulators, staged statistics -> histograms
-int launch_accumulate_staged(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,
-                             const uint32_t* stage_stats, bool with_histograms, void* stream, std::string* err);
-int launch_histogram_staged(const DScene& sc, uint32_t n_iterations, const uint32_t* stage_stats, void* stream, std::string* err);
+// The integrator's device code exists once per ARITHMETIC MODE (ptmi_device.hpp: strict / the reference's default OpenCL
+// build, PTMI_FLAG_DEFAULT_ARITHMETIC): kernels.hip and kernel_wavefront.hip are compiled twice and their entry points
+// carry the suffix `_da` in the default-arithmetic build.  A context picks one set (ptmi_api.cpp: kernels_of).
+#define PTMI_DECLARE_INTEGRATOR_ENTRY_POINTS(SUFFIX)                                                                             \
+    /* kernels.hip: one path per lane (kept for A/B and as a second implementation in the parity tests)                         \
+       iteration ids of a launch: first_iteration + k * iteration_stride, k < n_iterations */                                   \
+    int launch_render##SUFFIX(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, uint32_t iteration_stride,      \
+                              void* stream, std::string* err);                                                                  \
+    /* kernel_wavefront.hip: persistent wavefront state machine (default)                                                       \
+       stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30) */                        \
+    int wavefront_resident_blocks##SUFFIX(int device, uint32_t stack_levels);                                                    \
+    /* scene_in_device_memory = a device copy of `sc` (the kernel takes only the hot fields by value)                           \
+       stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself) */  \
+    int launch_render_wavefront##SUFFIX(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,        \
+                                        uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter,                \
+                                        int resident_blocks, uint32_t stack_levels, bool scheduler_stats, float* stage,         \
+                                        uint32_t* stage_stats, void* stream, std::string* err);                                 \
+    /* ... and what must follow it, in launch order: staged radiances -> accumulators, staged statistics -> histograms */       \
+    int launch_accumulate_staged##SUFFIX(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,  \
+                                         const uint32_t* stage_stats, bool with_histograms, void* stream, std::string* err);    \
+    int launch_histogram_staged##SUFFIX(const DScene& sc, uint32_t n_iterations, const uint32_t* stage_stats, void* stream,     \
+                                        std::string* err);
+PTMI_DECLARE_INTEGRATOR_ENTRY_POINTS()
+PTMI_DECLARE_INTEGRATOR_ENTRY_POINTS(_da)
+#undef PTMI_DECLARE_INTEGRATOR_ENTRY_POINTS
+// kernel_wavefront.hip, default-arithmetic build only: the reciprocal determinant of every DTriPre record (u_den[3]) as the
+// reference's default build computes it (FullKernel.cl:556 through v_rcp_f32: not reproducible on the host), written on
+// the device after the upload.  `tri_ids[i]` == 0xFFFFFFFF marks a node record.
+int launch_precompute_denominators_da(DTri* records, const uint32_t* tri_ids, uint32_t n_records, void* stream, std::string* err);
 
 // display.hip: accumulators -> padded B,G,R scanlines (the reference's ConvertRGBAToBMPBuffer), on the device
 int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint8_t* out, uint32_t width, uint32_t height,

@@ -3,7 +3,7 @@
 
 #include "ptmi_device.hpp"
 
-namespace ptmi_dev {
+namespace PTMI_DEV_NS {
 
 struct Surface {
     V4 Ng, Ns, color;
@@ -31,14 +31,14 @@ __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, con
         sf.color = v4(sf.mat.color);
     } else {
         const float* uv = hit.front ? sh->uvp : sh->uvn;
-        const float tu = (uv[0] * b + uv[2] * hit.s) + uv[4] * hit.t;
-        const float tv = (uv[1] * b + uv[3] * hit.s) + uv[5] * hit.t;
+        const float tu = mad(uv[4], hit.t, mad(uv[0], b, uv[2] * hit.s));  // cl:600 (UV1*(1-s-t)) + (UV2*s) + (UV3*t)
+        const float tv = mad(uv[5], hit.t, mad(uv[1], b, uv[3] * hit.s));
         sf.color = texture_pixel(sc.textures[sf.mat.texture_id], sc.texels, tu, tv);
     }
 
     const bool same_dir = dot(r.d, N) > 0;                       // :1267
     sf.Ng = same_dir ? -N : N;                                   // Triangle_GetNormal, header.cl:500
-    V4 Ns = normalize(((N2 * hit.s) + (N3 * hit.t)) + (N1 * b)); // Triangle_GetSmoothNormal, :604-610
+    V4 Ns = normalize(mad(N1, b, mad(N2, hit.s, N3 * hit.t)));   // Triangle_GetSmoothNormal, :604-610
     if (same_dir) Ns = -Ns;
     Ns = put_in_same_hemisphere(Ns, -r.d);                       // :1273
     sf.Ns = normalize(Ns);                                       // :1274
@@ -62,7 +62,8 @@ __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& i
         diffuse = true;
         N = sf.Ns;
     } else if (type == PTMI_MAT_GLASS) {
-        const float f = fresnel_fraction(1, kNGlass, -dot(r.d, sf.Ns), r.d, sf.Ns, nullptr);
+        constexpr DivC by_n_glass = make_divc(kNGlass);
+        const float f = fresnel_fraction(1, kNGlass, by_n_glass, -dot(r.d, sf.Ns), r.d, sf.Ns, nullptr);
         if (lcg_random(seed) < f) {
             out = reflect_about(r.d, sf.Ns);
             N = sf.Ng;
@@ -73,7 +74,7 @@ __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& i
     } else if (type == PTMI_MAT_WATER) {
         V4 refracted = v4(0, 0, 0, 0);
         const float n1 = in_water ? kNWater : 1.f, n2 = in_water ? 1.f : kNWater;
-        const float f = fresnel_fraction(n1, n2, -dot(r.d, sf.Ns), r.d, sf.Ns, &refracted);
+        const float f = fresnel_fraction(n1, n2, n2, -dot(r.d, sf.Ns), r.d, sf.Ns, &refracted);
         if (lcg_random(seed) < f) {
             out = reflect_about(r.d, sf.Ns);
             N = sf.Ng;
@@ -81,10 +82,10 @@ __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& i
             in_water = !in_water;
             out = refracted;
             N = -sf.Ng;
-            transfer = transfer * ((n2 * n2) / (n1 * n1));
+            transfer = transfer * fdiv(n2 * n2, n1 * n1);  // cl:251
         }
     } else if (type == PTMI_MAT_VARNHISHED) {
-        radiance = radiance + ((direct * sf.color) * transfer);
+        radiance = mad(direct * sf.color, transfer, radiance);  // cl:849
         const float f1 = fresnel_varnish(r.d, sf.Ns);
         if (lcg_random(seed) < f1) {
             out = reflect_about(r.d, sf.Ns);
@@ -104,7 +105,7 @@ __device__ __forceinline__ V4 scatter(Ray& r, int& seed, bool& in_water, const H
     V4 out;
     const V4 radiance = scatter_direction(r, seed, in_water, sf, direct, transfer, out);
     ray_set_direction(r, out);
-    r.o = hit.point + out * 0.001f;  // :880 uses the un-normalised direction
+    r.o = mad(out, 0.001f, hit.point);  // :880 uses the un-normalised direction
     return radiance;
 }
 
@@ -117,10 +118,10 @@ __device__ __forceinline__ bool path_continues(V4& transfer, uint32_t reflection
     if (m <= kMinContribution) return false;
     bool active = true;
     if (russian_roulette && reflection > 5u) {  // MIN_REFLECTION_NUMBER, header.cl:13
-        const float coeff = m / (float)(reflection - 5u);
+        const float coeff = fdiv(m, (float)(reflection - 5u));
         if (coeff < 1) {
             active = lcg_random(seed) > coeff;
-            transfer = transfer / coeff;
+            transfer = V4{fdiv(transfer.x, coeff), fdiv(transfer.y, coeff), fdiv(transfer.z, coeff), fdiv(transfer.w, coeff)};
         }
     }
     return active;
@@ -131,14 +132,17 @@ template <class SceneT>
 __device__ __forceinline__ void draw_sample(const SceneT& sc, uint32_t gx, uint32_t gy, uint32_t iteration, int& seed,
                                             float& sx, float& sy)
 {
+    // IMAGE_WIDTH / IMAGE_HEIGHT are constants of the reference's program (-D, OpenCL.cpp:296-299): constant divisors
+    const DivC by_w = make_divc((float)sc.width), by_h = make_divc((float)sc.height);
     if (sc.sampler == PTMI_SAMPLER_UNIFORM) {
+        constexpr DivC by_3 = make_divc(3.f);
         const int sample_id = (int)(iteration % 9u);
         sx = (float)gx; sy = (float)gy;
         float ox = (float)(sample_id % 3), oy = (float)(sample_id / 3);
         ox += 0.5f; oy += 0.5f;
-        ox /= 3.f; oy /= 3.f;
+        ox = fdiv(ox, by_3); oy = fdiv(oy, by_3);
         sx += ox; sy += oy;
-        sx /= (float)sc.width; sy /= (float)sc.height;
+        sx = fdiv(sx, by_w); sy = fdiv(sy, by_h);
         sx -= 0.5f; sy -= 0.5f;
     } else if (sc.sampler == PTMI_SAMPLER_RANDOM) {
         sx = lcg_random(seed);
@@ -147,8 +151,8 @@ __device__ __forceinline__ void draw_sample(const SceneT& sc, uint32_t gx, uint3
         sx += 0.05f; sy += 0.05f;
         sx -= 0.5f; sy -= 0.5f;
     } else {
-        sx = (((float)gx + 0.9f * lcg_random(seed)) + 0.05f) / (float)sc.width - 0.5f;
-        sy = (((float)gy + 0.9f * lcg_random(seed)) + 0.05f) / (float)sc.height - 0.5f;
+        sx = fdiv(mad(0.9f, lcg_random(seed), (float)gx) + 0.05f, by_w) - 0.5f;  // cl:1145
+        sy = fdiv(mad(0.9f, lcg_random(seed), (float)gy) + 0.05f, by_h) - 0.5f;
     }
 }
 
@@ -163,4 +167,4 @@ __device__ __forceinline__ uint32_t sample_pixel(const SceneT& sc, float sx, flo
     return (uint32_t)py * sc.width + (uint32_t)px;
 }
 
-}  // namespace ptmi_dev
+}  // namespace PTMI_DEV_NS

@@ -9,7 +9,25 @@
  *
  * Build with -O2 -ffp-contract=off and WITHOUT -march=native / -ffast-math:
  * every + - * / sqrt below must be one correctly rounded binary32 operation.
+ *
+ * TWO BUILDS of this file (oracle/Makefile), one per arithmetic the reference's source can be compiled to on this platform:
+ *   libpt_oracle.so      PTO_DEFAULT_ARITHMETIC 0: the STRICT build of the reference kernel (-ffp-contract=off
+ *                        -cl-fp32-correctly-rounded-divide-sqrt): every operation of the source correctly rounded;
+ *   libpt_oracle_da.so   PTO_DEFAULT_ARITHMETIC 1: the build the reference's OWN build line produces (OpenCL_BuildOptions,
+ *                        OpenCL.cpp:292-314: no floating-point option = OpenCL default arithmetic), as clang's OpenCL front
+ *                        end and the gfx950 back end compile it (established from the LLVM IR and the ISA of
+ *                        oracle/_ref/ref_kernel_*.hsaco):
+ *                          - `a * b + c` inside one expression (also `x += a * b`) is ONE fused multiply-add: mad() below,
+ *                            at exactly the sites where the front end emits llvm.fmuladd (left operand tried first);
+ *                          - a / b = ldexp(frexp_mant(a) * v_rcp_f32(frexp_mant(b)), frexp_exp(a) - frexp_exp(b)); a
+ *                            constant divisor's reciprocal mantissa is folded at compile time (correctly rounded): fdivc();
+ *                          - sqrt(x) = v_sqrt_f32 (behind a 2^32 scaling of denormal inputs).
+ *                        v_rcp_f32 and v_sqrt_f32 are not correctly rounded; like v_rsq_f32 they are reproduced from
+ *                        tables measured on an MI355X (tests/golden/rcp_gfx950.npz, sqrt_gfx950.npz).
  */
+#ifndef PTO_DEFAULT_ARITHMETIC
+#define PTO_DEFAULT_ARITHMETIC 0
+#endif
 #include "pt_oracle.h"
 #include "ptmi_detmath.h"
 
@@ -30,8 +48,12 @@ static inline f4 add4(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, 
 static inline f4 sub4(f4 a, f4 b) { return mk4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 static inline f4 mul4(f4 a, f4 b) { return mk4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 static inline f4 scale4(f4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
-static inline f4 div4s(f4 a, float s) { return mk4(a.x / s, a.y / s, a.z / s, a.w / s); }
+static inline float fdiv(float a, float b);
+static inline f4 div4s(f4 a, float s) { return mk4(fdiv(a.x, s), fdiv(a.y, s), fdiv(a.z, s), fdiv(a.w, s)); }
 static inline f4 neg4(f4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
+static inline float mad(float a, float b, float c);
+static inline f4 mad4(f4 a, f4 b, f4 c) { return mk4(mad(a.x, b.x, c.x), mad(a.y, b.y, c.y), mad(a.z, b.z, c.z), mad(a.w, b.w, c.w)); }
+static inline f4 mad4s(f4 a, float s, f4 c) { return mk4(mad(a.x, s, c.x), mad(a.y, s, c.y), mad(a.z, s, c.z), mad(a.w, s, c.w)); }
 
 /* The OpenCL geometric builtins are implementation-defined in their last bits.  They are fixed here to
  * the definitions of the OpenCL library the reference meets on this hardware (ROCm device libs, opencl.bc:
@@ -47,7 +69,106 @@ static inline f4 neg4(f4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
  *                  handed over with pto_set_rsq_table).
  * fmaf() is the correctly rounded fused multiply-add (one rounding), whatever -ffp-contract says. */
 static inline float dot4(f4 a, f4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
-static inline float length4(f4 a) { return sqrtf(dot4(a, a)); }
+
+/* ---- the arithmetic of the two builds (see the header) ---- */
+static const uint8_t *g_rcp_table, *g_sqrt_table; /* 2 bits per entry, as g_rsq_table below */
+void pto_set_rcp_table(const uint8_t* packed) { g_rcp_table = packed; }
+void pto_set_sqrt_table(const uint8_t* packed) { g_sqrt_table = packed; }
+int pto_default_arithmetic(void) { return PTO_DEFAULT_ARITHMETIC; }
+
+static inline int table_deviation(const uint8_t* table, uint32_t idx) { return (int)((table[idx >> 2] >> ((idx & 3u) * 2u)) & 3u) - 1; }
+static inline float nudge(float r, int ulps)
+{
+    uint32_t rb;
+    memcpy(&rb, &r, 4);
+    rb = (uint32_t)((int32_t)rb + ulps);
+    memcpy(&r, &rb, 4);
+    return r;
+}
+
+/* v_frexp_mant_f32 / v_frexp_exp_i32_f32: mantissa in +-[0.5, 1) and its exponent; zero, infinities and NaN pass through
+ * with exponent 0 */
+static inline float hw_frexp_mant(float x, int* e)
+{
+    *e = 0;
+    if (x == 0.0f || isinf(x) || x != x) return x;
+    return frexpf(x, e);
+}
+/* v_rcp_f32 on gfx950 for what v_frexp_mant_f32 can hand it */
+float pto_hardware_rcp(float m)
+{
+    uint32_t bits;
+    float r;
+    if (m != m) return m;
+    if (m == 0.0f) return copysignf(INFINITY, m);
+    if (isinf(m)) return copysignf(0.0f, m);
+    memcpy(&bits, &m, 4);
+    if (!g_rcp_table || (bits & 0x7F800000u) != 0x3F000000u) abort(); /* no table handed over / not a mantissa in [0.5, 1) */
+    r = (float)(1.0 / (double)fabsf(m));
+    r = nudge(r, table_deviation(g_rcp_table, bits & 0x7FFFFFu));
+    return copysignf(r, m);
+}
+/* v_sqrt_f32 on gfx950 for a normal, zero, infinite or negative input */
+float pto_hardware_sqrt(float x)
+{
+    uint32_t bits, rb;
+    int e, parity;
+    float red, r;
+    if (x != x) return x;
+    if (x == 0.0f) return x;
+    if (x < 0.0f) return NAN;
+    if (isinf(x)) return x;
+    memcpy(&bits, &x, 4);
+    e = (int)(bits >> 23) - 127;
+    if (!g_sqrt_table || e == -127) abort(); /* no table handed over / denormal input (fsqrt scales first) */
+    parity = e & 1; /* x = red * 2^(e - parity), red in [1,2) or [2,4), e - parity even */
+    rb = (parity ? 0x40000000u : 0x3F800000u) | (bits & 0x7FFFFFu);
+    memcpy(&red, &rb, 4);
+    r = (float)sqrt((double)red);
+    r = nudge(r, table_deviation(g_sqrt_table, ((uint32_t)parity << 23) | (bits & 0x7FFFFFu)));
+    return ldexpf(r, (e - parity) / 2); /* exact */
+}
+
+/* a * b + c written in one expression of the reference */
+static inline float mad(float a, float b, float c)
+{
+#if PTO_DEFAULT_ARITHMETIC
+    return fmaf(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+/* a / b, b a run-time value */
+static inline float fdiv(float a, float b)
+{
+#if PTO_DEFAULT_ARITHMETIC
+    int ea, eb;
+    const float ma = hw_frexp_mant(a, &ea), mb = hw_frexp_mant(b, &eb);
+    return ldexpf(ma * pto_hardware_rcp(mb), ea - eb);
+#else
+    return a / b;
+#endif
+}
+/* a / c, c a constant of the reference's program (a literal, IMAGE_WIDTH, IMAGE_HEIGHT): positive and normal */
+static inline float fdivc(float a, float c)
+{
+#if PTO_DEFAULT_ARITHMETIC
+    int ea, ec;
+    const float ma = hw_frexp_mant(a, &ea), mc = frexpf(c, &ec);
+    return ldexpf(ma * (1.0f / mc), ea - ec);
+#else
+    return a / c;
+#endif
+}
+static inline float fsqrt(float x)
+{
+#if PTO_DEFAULT_ARITHMETIC
+    if (x < 0x1p-126f) return ldexpf(pto_hardware_sqrt(ldexpf(x, 32)), -16);
+    return pto_hardware_sqrt(x);
+#else
+    return sqrtf(x);
+#endif
+}
 
 static const uint8_t* g_rsq_table; /* 2 bits per entry: 0 = one ulp below, 1 = equal, 2 = one ulp above the correctly rounded value */
 void pto_set_rsq_table(const uint8_t* packed) { g_rsq_table = packed; }
@@ -107,6 +228,26 @@ static inline f4 normalize4(f4 a)
         }
     }
     return scale4(a, cl_rsqrt(d));
+}
+/* _Z6lengthDv4_f of opencl.bc: sqrt(dot) with a rescaling for squared lengths outside the normal range (which only matters
+ * for the default build's hardware square root; the strict build's is correctly rounded either way and a light distance
+ * never leaves the range) */
+static inline float length4(f4 a)
+{
+    const float d = dot4(a, a);
+#if PTO_DEFAULT_ARITHMETIC
+    if (d < 0x1p-126f) {
+        a = scale4(a, 0x1p+86f);
+        return fsqrt(dot4(a, a)) * 0x1p-86f;
+    }
+    if (d == INFINITY) {
+        a = scale4(a, 0x1p-66f);
+        return fsqrt(dot4(a, a)) * 0x1p+66f;
+    }
+    return pto_hardware_sqrt(d);
+#else
+    return sqrtf(d);
+#endif
 }
 static inline f4 cross4(f4 a, f4 b)
 {
@@ -177,9 +318,9 @@ void pto_sampler(uint32_t kind, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h
         float sx = (float)gx, sy = (float)gy;
         float ox = (float)(sample_id % 3), oy = (float)(sample_id / 3);
         ox += 0.5f; oy += 0.5f;
-        ox /= 3.f;  oy /= 3.f;
+        ox = fdivc(ox, 3.f); oy = fdivc(oy, 3.f);
         sx += ox;   sy += oy;
-        sx /= (float)w; sy /= (float)h;
+        sx = fdivc(sx, (float)w); sy = fdivc(sy, (float)h);
         sx -= 0.5f; sy -= 0.5f;
         sample[0] = sx; sample[1] = sy;
     } else if (kind == PTMI_SAMPLER_RANDOM) { /* cl:1137-1141 */
@@ -190,8 +331,8 @@ void pto_sampler(uint32_t kind, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h
         sx -= 0.5f;  sy -= 0.5f;
         sample[0] = sx; sample[1] = sy;
     } else { /* JITTERED, cl:1145-1146 */
-        sample[0] = (((float)gx + 0.9f * pto_random(seed)) + 0.05f) / (float)w - 0.5f;
-        sample[1] = (((float)gy + 0.9f * pto_random(seed)) + 0.05f) / (float)h - 0.5f;
+        sample[0] = fdivc(mad(0.9f, pto_random(seed), (float)gx) + 0.05f, (float)w) - 0.5f;
+        sample[1] = fdivc(mad(0.9f, pto_random(seed), (float)gy) + 0.05f, (float)h) - 0.5f;
     }
 }
 
@@ -202,9 +343,9 @@ void pto_sampler(uint32_t kind, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h
 static void ray_set_direction(ray_t* r, f4 d)
 {
     r->direction = normalize4(d);
-    r->inverse.x = 1.0f / r->direction.x;
-    r->inverse.y = 1.0f / r->direction.y;
-    r->inverse.z = 1.0f / r->direction.z;
+    r->inverse.x = fdiv(1.0f, r->direction.x);
+    r->inverse.y = fdiv(1.0f, r->direction.y);
+    r->inverse.z = fdiv(1.0f, r->direction.z);
     r->inverse.w = 0.0f;
 }
 
@@ -224,7 +365,7 @@ static void ray_create(ray_t* r, f4 o, f4 d, int in_water)
 static f4 put_in_same_hemisphere(f4 v, f4 n)
 {
     const float d = dot4(v, n);
-    if (d < 0.001f) v = add4(v, scale4(n, 0.01f - d));
+    if (d < 0.001f) v = mad4s(n, 0.01f - d, v); /* h:241 */
     return v;
 }
 
@@ -291,7 +432,7 @@ static f4 texture_pixel(const ptmi_texture* tex, const ptmi_uchar4* data, float 
     {
         const uint32_t index = tex->offset + y * tex->width + x;
         const ptmi_uchar4 p = data[index];
-        f4 c = mk4((float)p.x / 255.f, (float)p.y / 255.f, (float)p.z / 255.f, (float)p.w / 255.f);
+        f4 c = mk4(fdivc((float)p.x, 255.f), fdivc((float)p.y, 255.f), fdivc((float)p.z, 255.f), fdivc((float)p.w, 255.f));
         c.w = 1.f - c.w;
         return c;
     }
@@ -299,21 +440,21 @@ static f4 texture_pixel(const ptmi_texture* tex, const ptmi_uchar4* data, float 
 
 static f4 sky_color(const ptmi_sky* sky, const ptmi_uchar4* data, f4 d)
 {
-    const float x = sky->cos_rotation_angle * d.x - sky->sin_rotation_angle * d.y;
-    const float y = sky->sin_rotation_angle * d.x + sky->cos_rotation_angle * d.y;
+    const float x = mad(sky->cos_rotation_angle, d.x, -(sky->sin_rotation_angle * d.y)); /* cl:441 */
+    const float y = mad(sky->sin_rotation_angle, d.x, sky->cos_rotation_angle * d.y);    /* cl:442 */
     const float z = d.z;
     int face = 0;
     float u = 0, v = 0;
 
     if (fabsf(z) > fabsf(x) && fabsf(z) > fabsf(y)) {
-        if (z > 0) { face = 5; u = (1 - x / z) / 2; v = (1 + y / z) / 2; }
-        else       { face = 0; u = (1 + x / z) / 2; v = (1 + y / z) / 2; }
+        if (z > 0) { face = 5; u = (1 - fdiv(x, z)) / 2; v = (1 + fdiv(y, z)) / 2; }
+        else       { face = 0; u = (1 + fdiv(x, z)) / 2; v = (1 + fdiv(y, z)) / 2; }
     } else if (fabsf(x) > fabsf(y) && fabsf(x) > fabsf(z)) {
-        if (x > 0) { face = 1; u = (1 - y / x) / 2; v = (1 + z / x) / 2; }
-        else       { face = 3; u = (1 - y / x) / 2; v = (1 - z / x) / 2; }
+        if (x > 0) { face = 1; u = (1 - fdiv(y, x)) / 2; v = (1 + fdiv(z, x)) / 2; }
+        else       { face = 3; u = (1 - fdiv(y, x)) / 2; v = (1 - fdiv(z, x)) / 2; }
     } else if (fabsf(y) > fabsf(x) && fabsf(y) > fabsf(z)) {
-        if (y > 0) { face = 4; u = (1 + x / y) / 2; v = (1 + z / y) / 2; }
-        else       { face = 2; u = (1 + x / y) / 2; v = (1 - z / y) / 2; }
+        if (y > 0) { face = 4; u = (1 + fdiv(x, y)) / 2; v = (1 + fdiv(z, y)) / 2; }
+        else       { face = 2; u = (1 + fdiv(x, y)) / 2; v = (1 - fdiv(z, y)) / 2; }
     }
     return texture_pixel(&sky->sky_textures[face], data, u, v); /* Sky_GetFaceColorValue, cl:497-512 */
 }
@@ -330,11 +471,11 @@ static f4 triangle_color_at(const pto_scene* sc, const ptmi_triangle* tri, int p
     const float b = (1 - s) - t;
     if (mat->is_simple_color) return ld4(&mat->simple_color);
     if (positive_normal) {
-        u = (tri->uvp1.x * b + tri->uvp2.x * s) + tri->uvp3.x * t;
-        v = (tri->uvp1.y * b + tri->uvp2.y * s) + tri->uvp3.y * t;
+        u = mad(tri->uvp3.x, t, mad(tri->uvp1.x, b, tri->uvp2.x * s)); /* cl:600 */
+        v = mad(tri->uvp3.y, t, mad(tri->uvp1.y, b, tri->uvp2.y * s));
     } else {
-        u = (tri->uvn1.x * b + tri->uvn2.x * s) + tri->uvn3.x * t;
-        v = (tri->uvn1.y * b + tri->uvn2.y * s) + tri->uvn3.y * t;
+        u = mad(tri->uvn3.x, t, mad(tri->uvn1.x, b, tri->uvn2.x * s));
+        v = mad(tri->uvn3.y, t, mad(tri->uvn1.y, b, tri->uvn2.y * s));
     }
     return texture_pixel(&sc->textures[mat->texture_id], sc->textures_data, u, v);
 }
@@ -357,7 +498,7 @@ static int triangle_intersects(const pto_scene* sc, const ptmi_triangle* tri, ra
 
         if ((nd > -0.00001f) && (nd < 0.00001f)) return 0;
 
-        q = add4(r->origin, scale4(r->direction, (d - dot4(N, r->origin)) / nd));
+        q = mad4s(r->direction, fdiv(d - dot4(N, r->origin), nd), r->origin); /* cl:538 */
         full_ray = sub4(q, r->origin);
         nsd = dot4(full_ray, full_ray);
         if (nsd > *squared_distance) return 0;
@@ -365,9 +506,9 @@ static int triangle_intersects(const pto_scene* sc, const ptmi_triangle* tri, ra
 
         w = sub4(q, S1);
         uv = dot4(u, v); wv = dot4(w, v); wu = dot4(w, u); uu = dot4(u, u); vv = dot4(v, v);
-        denom = 1 / (uv * uv - uu * vv);
-        s = (uv * wv - vv * wu) * denom;
-        t = (uv * wu - uu * wv) * denom;
+        denom = fdiv(1, mad(uv, uv, -(uu * vv))); /* cl:556 */
+        s = mad(uv, wv, -(vv * wu)) * denom;      /* cl:558 */
+        t = mad(uv, wu, -(uu * wv)) * denom;      /* cl:559 */
         if (s < 0 || t < 0 || s + t > 1) return 0;
         if (dot4(full_ray, r->direction) < 0) return 0;
 
@@ -384,8 +525,8 @@ static int triangle_intersects(const pto_scene* sc, const ptmi_triangle* tri, ra
 /* Triangle_GetSmoothNormal, cl:604-610 */
 static f4 triangle_smooth_normal(const ptmi_triangle* tri, int positive_normal, float s, float t)
 {
-    const f4 n = normalize4(add4(add4(scale4(ld4(&tri->n2), s), scale4(ld4(&tri->n3), t)),
-                                 scale4(ld4(&tri->n1), (1 - s) - t)));
+    /* cl:606: (N2 * s) + (N3 * t) + (N1 * (1 - s - t)) */
+    const f4 n = normalize4(mad4s(ld4(&tri->n1), (1 - s) - t, mad4s(ld4(&tri->n2), s, scale4(ld4(&tri->n3), t))));
     return positive_normal ? n : neg4(n);
 }
 
@@ -493,24 +634,28 @@ static int bvh_intersect_shadow_ray(const pto_scene* sc, ray_t* r, float squared
 /* ------------------------------------------------------------------------- */
 
 /* shared body of the three Fresnel functions (cl:192-292) */
-static float fresnel_fraction(float n1, float n2, float cos1, f4 incident, f4 N, f4* refraction_dir)
+/* n2_is_literal: the glass and varnish functions divide by a literal (1.55f, 3.f), the water function by a value selected at
+ * run time (cl:223-232) - the default build divides differently by the two (fdivc / fdiv) */
+static float fresnel_fraction(float n1, float n2, int n2_is_literal, float cos1, f4 incident, f4 N, f4* refraction_dir)
 {
-    const float sin1 = sqrtf(1 - cos1 * cos1);
-    const float sin2 = n1 * sin1 / n2;
+    const float sin1 = fsqrt(mad(-cos1, cos1, 1));
+    const float sin2 = n2_is_literal ? fdivc(n1 * sin1, n2) : fdiv(n1 * sin1, n2);
     float cos2, r_para, r_perp;
     if (sin2 >= 1) return 1;
-    cos2 = sqrtf(1 - sin2 * sin2);
-    r_para = (n2 * cos1 - n1 * cos2) / (n2 * cos1 + n1 * cos2);
-    r_perp = (n1 * cos1 - n2 * cos2) / (n1 * cos1 + n2 * cos2);
-    if (refraction_dir)
-        *refraction_dir = add4(scale4(incident, n1 / n2), scale4(N, n1 / n2 * cos1 - cos2)); /* cl:249,289 */
-    return (r_para * r_para + r_perp * r_perp) / 2.0f;
+    cos2 = fsqrt(mad(-sin2, sin2, 1));
+    r_para = fdiv(mad(n2, cos1, -(n1 * cos2)), mad(n2, cos1, n1 * cos2));
+    r_perp = fdiv(mad(n1, cos1, -(n2 * cos2)), mad(n1, cos1, n2 * cos2));
+    if (refraction_dir) { /* cl:249 (live for water only: n1 / n2 of run-time values) */
+        const float ratio = fdiv(n1, n2);
+        *refraction_dir = mad4s(incident, ratio, scale4(N, mad(ratio, cos1, -cos2)));
+    }
+    return mad(r_para, r_para, r_perp * r_perp) / 2.0f;
 }
 
 /* Material_FresnelGlassReflectionFraction, cl:192-217 */
 static float fresnel_glass(f4 incident, f4 N)
 {
-    return fresnel_fraction(1, MATERIAL_N_GLASS, -dot4(incident, N), incident, N, NULL);
+    return fresnel_fraction(1, MATERIAL_N_GLASS, 1, -dot4(incident, N), incident, N, NULL);
 }
 
 /* Material_FresnelWaterReflectionFraction, cl:219-254.  On total reflection the
@@ -521,8 +666,8 @@ static float fresnel_water(f4 incident, f4 N, int already_in_water, f4* refracti
 {
     float n1, n2, f;
     if (already_in_water) { n1 = MATERIAL_N_WATER; n2 = 1; } else { n1 = 1; n2 = MATERIAL_N_WATER; }
-    f = fresnel_fraction(n1, n2, -dot4(incident, N), incident, N, refraction_dir);
-    if (mult) *mult = (n2 * n2) / (n1 * n1);
+    f = fresnel_fraction(n1, n2, 0, -dot4(incident, N), incident, N, refraction_dir);
+    if (mult) *mult = fdiv(n2 * n2, n1 * n1);
     return f;
 }
 
@@ -530,11 +675,12 @@ static float fresnel_water(f4 incident, f4 N, int already_in_water, f4* refracti
 static float fresnel_varnish(f4 incident, f4 N, f4* refraction_dir)
 {
     const float cos1 = fmaxf(0.f, fminf(1.f, -dot4(incident, N)));
-    return fresnel_fraction(1.0f, MATERIAL_N_VARNISH, cos1, incident, N, refraction_dir);
+    (void)refraction_dir; /* computed by the reference, never read (cl:856) */
+    return fresnel_fraction(1.0f, MATERIAL_N_VARNISH, 1, cos1, incident, N, NULL);
 }
 
 /* Material_FresnelReflection, cl:294-300 */
-static f4 fresnel_reflection(f4 v, f4 N) { return sub4(v, scale4(N, 2 * dot4(v, N))); }
+static f4 fresnel_reflection(f4 v, f4 N) { return mad4s(neg4(N), 2 * dot4(v, N), v); } /* cl:298 */
 
 /* Material_BRDF, cl:166-190 */
 static float material_brdf(const ptmi_material* mat, f4 incident, f4 N, f4 reflected)
@@ -542,8 +688,8 @@ static float material_brdf(const ptmi_material* mat, f4 incident, f4 N, f4 refle
     if (mat->type == PTMI_MAT_STANDART) return PATH_PI_INVERSE;
     if (mat->type == PTMI_MAT_GLASS) return 1;
     if (mat->type == PTMI_MAT_WATER) {
-        const float denom = 1 + MATERIAL_KSCHLICK * dot4(incident, reflected);
-        return (1 - MATERIAL_KSCHLICK * MATERIAL_KSCHLICK) / (4 * PATH_PI * denom * denom);
+        const float denom = mad(MATERIAL_KSCHLICK, dot4(incident, reflected), 1);
+        return fdiv(1 - MATERIAL_KSCHLICK * MATERIAL_KSCHLICK, 4 * PATH_PI * denom * denom);
     }
     if (mat->type == PTMI_MAT_VARNHISHED) return (1 - fresnel_varnish(incident, N, NULL)) * PATH_PI_INVERSE;
     return 1;
@@ -555,17 +701,17 @@ void pto_concentric_sample_disk(int32_t* seed, float* dx, float* dy)
     const float u1 = pto_random(seed);
     const float u2 = pto_random(seed);
     float r, theta, sn, cs;
-    const float sx = 2 * u1 - 1;
-    const float sy = 2 * u2 - 1;
+    const float sx = mad(2, u1, -1); /* cl:350 */
+    const float sy = mad(2, u2, -1);
 
     if (fabsf(sx) < 0.0001f) { r = sy; theta = 0; }
     else if (fabsf(sy) < 0.0001f) { r = sx; theta = 2; }
     else if (sx > -sy) {
-        if (sx > sy) { r = sx; if (sy > 0) theta = sy / sx; else theta = 8.f + sy / sx; }
-        else { r = sy; theta = 2.f - sx / sy; }
+        if (sx > sy) { r = sx; if (sy > 0) theta = fdiv(sy, sx); else theta = 8.f + fdiv(sy, sx); }
+        else { r = sy; theta = 2.f - fdiv(sx, sy); }
     } else {
-        if (sx < sy) { r = -sx; theta = 4.f + sy / sx; }
-        else { r = -sy; theta = 6.f - sy / sx; }
+        if (sx < sy) { r = -sx; theta = 4.f + fdiv(sy, sx); }
+        else { r = -sy; theta = 6.f - fdiv(sy, sx); }
     }
     theta *= PATH_PI / 4.f;
     r = (float)((double)r * 0.999); /* cl:408: unsuffixed literal => double multiply */
@@ -580,7 +726,10 @@ static f4 cosine_sample_hemisphere(int32_t* seed, f4 N)
     float x, y, z;
     f4 v, sn, tn;
     pto_concentric_sample_disk(seed, &x, &y);
-    z = 1 - x * x - y * y;
+    z = mad(-y, y, mad(-x, x, 1)); /* cl:311 */
+    /* correctly rounded in BOTH builds: the optimizer turns `(z<0) ? 0 : sqrt(z)` (cl:312) into a select and the speculated
+     * call loses the !fpmath annotation that makes every other sqrt of the default build v_sqrt_f32 (seen in the optimized
+     * IR of the reference kernel: llvm.sqrt without !fpmath at exactly this site) */
     z = (z < 0) ? 0 : sqrtf(z);
     v = mk4(x, y, z, 0);
     if (N.z > 0.9999f) return v;
@@ -599,14 +748,14 @@ static float light_power_toward(const ptmi_light* l, f4 p, f4 N)
     if (l->type == PTMI_LIGHT_DIRECTIONNAL) return l->power * fmaxf(dot4(neg4(dir), N), 0.f);
     if (l->type == PTMI_LIGHT_POINT) {
         const f4 d = sub4(p, pos); /* Vector_SquaredDistanceTo(&position, p): temp = p - position, h:231 */
-        return l->power / dot4(d, d) * fmaxf(dot4(normalize4(sub4(pos, p)), N), 0.f);
+        return fdiv(l->power, dot4(d, d)) * fmaxf(dot4(normalize4(sub4(pos, p)), N), 0.f);
     }
     if (l->type == PTMI_LIGHT_SPOT) {
         const f4 lrd = normalize4(sub4(p, pos));
         const float cos_angle = dot4(lrd, dir);
         if (cos_angle > l->cos_inner) return l->power * fmaxf(-dot4(lrd, N), 0.f);
         if (cos_angle < l->cos_outer) return 0.0f;
-        return l->power * (cos_angle - l->cos_outer) / (l->cos_inner - l->cos_outer) * fmaxf(-dot4(lrd, N), 0);
+        return fdiv(l->power * (cos_angle - l->cos_outer), l->cos_inner - l->cos_outer) * fmaxf(-dot4(lrd, N), 0);
     }
     return 0.f;
 }
@@ -633,7 +782,7 @@ static f4 compute_direct_illumination(const pto_scene* sc, ray_t* cam, const ptm
         brdf = material_brdf(mat, neg4(lr.direction), N, cam->direction);
         if (totals) totals->shadow_rays++;
         if (!bvh_intersect_shadow_ray(sc, &lr, light_distance))
-            L = add4(L, mul4(scale4(tint, light_power_toward(light, cam->point, N) * brdf), ld4(&light->color)));
+            L = mad4(scale4(tint, light_power_toward(light, cam->point, N) * brdf), ld4(&light->color), L); /* cl:945 */
         cam->num_bbx += lr.num_bbx;
         cam->num_tri += lr.num_tri;
     }
@@ -678,7 +827,7 @@ static f4 compute_radiance(ray_t* r, int32_t* seed, const ptmi_material* mat, f4
     } else if (mat->type == PTMI_MAT_VARNHISHED) {
         f4 refracted;
         float f1;
-        radiance = add4(radiance, mul4(mul4(direct, r->color), *transfer));
+        radiance = mad4(mul4(direct, r->color), *transfer, radiance); /* cl:849 */
         f1 = fresnel_varnish(r->direction, Ns, &refracted);
         if (pto_random(seed) < f1) {
             out = fresnel_reflection(r->direction, Ns);
@@ -690,7 +839,7 @@ static f4 compute_radiance(ray_t* r, int32_t* seed, const ptmi_material* mat, f4
 
     out = put_in_same_hemisphere(out, N);
     ray_set_direction(r, out);
-    r->origin = add4(r->point, scale4(out, 0.001f)); /* cl:880: the un-normalised out direction */
+    r->origin = mad4s(out, 0.001f, r->point); /* cl:880: the un-normalised out direction */
     if (out_dir_dbg) *out_dir_dbg = out;
     return radiance;
 }
@@ -716,14 +865,14 @@ static int super_sampling_stop(const pto_scene* sc, const pto_buffers* out, cons
     sample_to_pixel(sc, r->sample_x, r->sample_y, &px, &py);
     off = py * (int)sc->image_width + px;
     n = out->image_ray_nb[off];
-    sx = out->image_v[4 * off + 0] / n;
-    sy = out->image_v[4 * off + 1] / n;
-    sz = out->image_v[4 * off + 2] / n;
+    sx = fdiv(out->image_v[4 * off + 0], n);
+    sy = fdiv(out->image_v[4 * off + 1], n);
+    sz = fdiv(out->image_v[4 * off + 2], n);
     sigma2_n = fmaxf(fmaxf(sx, sy), sz);
     {
         uint32_t idx = (uint32_t)n;
         if (idx > 1000u) idx = 1000u; /* the reference reads past its 1001-entry table for n > 1000 (no clamp) */
-        return (double)pto_random(seed) > (double)(100 * sigma2_n / sc->x2inv[idx]) + 0.05;
+        return (double)pto_random(seed) > (double)fdiv(100 * sigma2_n, sc->x2inv[idx]) + 0.05;
     }
 }
 
@@ -742,8 +891,7 @@ static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint3
     int active = 1, n_trace = 0;
 
     pto_sampler(sc->sampler, gx, gy, sc->image_width, sc->image_height, iteration, &seed, sample);
-    shot = add4(add4(ld4(&sc->camera_direction), scale4(ld4(&sc->camera_right), sample[0])),
-                scale4(ld4(&sc->camera_up), sample[1]));
+    shot = mad4s(ld4(&sc->camera_up), sample[1], mad4s(ld4(&sc->camera_right), sample[0], ld4(&sc->camera_direction))); /* cl:1213 */
     ray_create(&r, ld4(&sc->camera_position), shot, 0);
     r.sample_x = sample[0];
     r.sample_y = sample[1];
@@ -778,14 +926,14 @@ static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint3
             }
         } else {
             active = 0;
-            radiance = add4(radiance, mul4(sky_color(sc->sky, sc->textures_data, r.direction), transfer));
+            radiance = mad4(sky_color(sc->sky, sc->textures_data, r.direction), transfer, radiance); /* cl:1287 */
         }
         if (active) { /* cl:1296-1304 */
             const float max_contribution = cl_max(transfer.x, cl_max(transfer.y, transfer.z));
             if (max_contribution <= MIN_CONTRIBUTION_VALUE) active = 0;
             /* cl:1306-1314, commented out in the reference (RUSSIAN_ROULETTE false, h:12): as written there */
             if (sc->russian_roulette && active && r.reflection_id > MIN_REFLECTION_NUMBER) {
-                const float coeff = max_contribution / (float)(r.reflection_id - MIN_REFLECTION_NUMBER);
+                const float coeff = fdiv(max_contribution, (float)(r.reflection_id - MIN_REFLECTION_NUMBER));
                 if (coeff < 1) {
                     active = active && (pto_random(&seed) > coeff);
                     transfer = div4s(transfer, coeff);
@@ -826,7 +974,7 @@ static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint3
             } else {
                 f4 v;
                 memcpy(&v, &out->image_v[4 * off], 16);
-                v = add4(v, mul4(sub4(radiance, div4s(before, n_before)), sub4(radiance, div4s(after, n_after))));
+                v = mad4(sub4(radiance, div4s(before, n_before)), sub4(radiance, div4s(after, n_after)), v); /* cl:1349 */
                 memcpy(&out->image_v[4 * off], &v, 16);
             }
         }
@@ -967,3 +1115,23 @@ void pto_sky_color(const ptmi_sky* sky, const ptmi_uchar4* data, const float dir
 }
 
 void pto_sincos(float x, float* s, float* c) { ptmi_sincosf(x, s, c); }
+
+/* the operators of oracle/arith_probe.cl in this build's arithmetic: out[k * n + i], k = 0..9 (GPU test: the default build of
+ * this file == the OpenCL compiler's output == the product's default-arithmetic mode) */
+void pto_arith_probe(const float* a, const float* b, uint32_t n, float* out)
+{
+    uint32_t i;
+    for (i = 0; i < n; i++) {
+        const float x = a[i], y = b[i];
+        out[0 * (size_t)n + i] = fdiv(x, y);
+        out[1 * (size_t)n + i] = fdiv(1.0f, x);
+        out[2 * (size_t)n + i] = fdivc(x, 255.f);
+        out[3 * (size_t)n + i] = fdivc(x, 3.f);
+        out[4 * (size_t)n + i] = fdivc(x, 1.55f);
+        out[5 * (size_t)n + i] = fdivc(x, (float)1920);
+        out[6 * (size_t)n + i] = fdivc(x, (float)90);
+        out[7 * (size_t)n + i] = fsqrt(x);
+        out[8 * (size_t)n + i] = length4(mk4(x, y, x * 0.5f, 0.0f));
+        out[9 * (size_t)n + i] = mad(x, y, 1.0f);
+    }
+}

@@ -121,6 +121,14 @@ void pto_sincos(float x, float* s, float* c);
  * Must be set before anything that normalises a vector is called. */
 void pto_set_rsq_table(const uint8_t* packed);
 float pto_hardware_rsq(float x);
+/* the default-arithmetic build's division and square root go through v_rcp_f32 / v_sqrt_f32 (pt_oracle.c header):
+ * tests/golden/rcp_gfx950.npz (2^23 entries), sqrt_gfx950.npz (2^24) */
+void pto_set_rcp_table(const uint8_t* packed);
+void pto_set_sqrt_table(const uint8_t* packed);
+float pto_hardware_rcp(float mantissa);
+float pto_hardware_sqrt(float x);
+int pto_default_arithmetic(void); /* which of the two builds this library is */
+void pto_arith_probe(const float* a, const float* b, uint32_t n, float* out); /* the ten operators of arith_probe.cl */
 
 #ifdef __cplusplus
 }

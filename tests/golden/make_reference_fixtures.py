@@ -33,9 +33,9 @@ def scene_digest(sc):
     return h.hexdigest()
 
 
-def main(out_dir):
+def main(out_dir, features_only=False):
     os.makedirs(out_dir, exist_ok=True)
-    for case, (name, sampler, w, h, d) in cases.CASES.items():
+    for case, (name, sampler, w, h, d) in ({} if features_only else cases.CASES).items():
         if not O.have_ref_kernel(case):
             print("skip", case, "(no code object)")
             continue
@@ -71,7 +71,8 @@ def main(out_dir):
         one, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1)
         out["it0_1_color"] = one
         np.savez_compressed(os.path.join(out_dir, f"ref_{case}.npz"), **out)
-    # one kernel feature per scene through the strict build: digests of image, counts and histograms (8 spp each)
+    # one kernel feature per scene through the strict build: digests of image, counts and histograms (8 spp each);
+    # `<feature>_default`: the same through the default build (what the reference's own build line produces)
     fcase, fw, fh, fd = cases.FEATURE_CASE
     if O.have_ref_kernel(fcase, strict=True):
         digests = {}
@@ -80,9 +81,12 @@ def main(out_dir):
             color, count, (dep, bbx, tri), _ = O.ref_gpu_render(fcase, sc, fw, fh, fd, cases.FEATURE_SPP, strict=True)
             digests[feature] = cases.result_digest(color, count, dep, bbx, tri)
             digests[feature + "_scene"] = scene_digest(sc)
-            print("feature", feature, digests[feature][:16], flush=True)
+            color, count, (dep, bbx, tri), _ = O.ref_gpu_render(fcase, sc, fw, fh, fd, cases.FEATURE_SPP)
+            digests[feature + "_default"] = cases.result_digest(color, count, dep, bbx, tri)
+            print("feature", feature, digests[feature][:16], digests[feature + "_default"][:16], flush=True)
         np.savez_compressed(os.path.join(out_dir, f"ref_{fcase}_features.npz"), **{k: np.array(v) for k, v in digests.items()})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden"))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    main(args[0] if args else os.path.join(ROOT, "gpurun_out", "golden"), features_only="--features-only" in sys.argv)

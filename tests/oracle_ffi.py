@@ -16,7 +16,8 @@ from opencl_pathtracer_amd import structs as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "build", "libpt_oracle.so")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "build", "libpt_oracle.so")         # the reference's strict build's arithmetic
+ORACLE_DA_LIB = os.path.join(ORACLE_DIR, "build", "libpt_oracle_da.so")  # ... its default build's (what its own build line gives)
 REF_DIR = os.path.join(ORACLE_DIR, "_ref")
 REF_BVH_LIB = os.path.join(REF_DIR, "libref_bvh.so")
 REF_GPU_LIB = os.path.join(REF_DIR, "libref_gpu_runner.so")
@@ -55,20 +56,32 @@ class PtoBounce(C.Structure):
                 ("n_bbx", C.c_uint32), ("n_tri", C.c_uint32)]
 
 
-_oracle = None
-_rsq_table = None  # kept alive: the oracle holds a pointer into it
+_oracle = {}
+_hw_tables = {}  # kept alive: the oracle holds pointers into them
 
 
 def build_oracle():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
 
-def oracle():
-    global _oracle
-    if _oracle is None:
-        if not os.path.exists(ORACLE_LIB):
+def _hw_table(kind, entries):
+    """2-bit deviations of a gfx950 instruction from the correctly rounded function (tests/golden/make_hw_tables.py)"""
+    if kind not in _hw_tables:
+        t = np.ascontiguousarray(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{kind}_gfx950.npz"))["packed"])
+        assert t.dtype == np.uint8 and t.size == entries // 4
+        _hw_tables[kind] = t
+    return _hw_tables[kind].ctypes.data_as(C.c_void_p)
+
+
+def oracle(default_arithmetic=False):
+    """The CPU restatement in the arithmetic of the reference's strict build, or (default_arithmetic) of the build its own
+    build line produces."""
+    path = ORACLE_DA_LIB if default_arithmetic else ORACLE_LIB
+    if default_arithmetic not in _oracle:
+        if not os.path.exists(path):
             build_oracle()
-        lib = C.CDLL(ORACLE_LIB)
+        lib = C.CDLL(path)
+        assert lib.pto_default_arithmetic() == (1 if default_arithmetic else 0)
         lib.pto_render.argtypes = [C.POINTER(PtoScene), C.c_uint32, C.c_uint32, C.POINTER(PtoBuffers), C.c_int,
                                    C.POINTER(PtoTotals)]
         lib.pto_render.restype = None
@@ -98,17 +111,16 @@ def oracle():
         lib.pto_cosine_sample_hemisphere.restype = None
         # normalize()'s reciprocal square root on the platform the reference runs on is a hardware instruction: the
         # oracle reproduces it from the table measured on an MI355X (tests/golden/make_rsq_table.py)
-        global _rsq_table
-        _rsq_table = np.ascontiguousarray(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                                               "rsq_gfx950.npz"))["packed"])
-        assert _rsq_table.dtype == np.uint8 and _rsq_table.size == 1 << 22
-        lib.pto_set_rsq_table.argtypes = [C.c_void_p]
-        lib.pto_set_rsq_table.restype = None
-        lib.pto_set_rsq_table(_rsq_table.ctypes.data_as(C.c_void_p))
-        lib.pto_hardware_rsq.argtypes = [C.c_float]
-        lib.pto_hardware_rsq.restype = C.c_float
-        _oracle = lib
-    return _oracle
+        for kind, entries in (("rsq", 1 << 24), ("rcp", 1 << 23), ("sqrt", 1 << 24)):
+            setter = getattr(lib, f"pto_set_{kind}_table")
+            setter.argtypes = [C.c_void_p]
+            setter.restype = None
+            setter(_hw_table(kind, entries))
+            fn = getattr(lib, f"pto_hardware_{kind}")
+            fn.argtypes = [C.c_float]
+            fn.restype = C.c_float
+        _oracle[default_arithmetic] = lib
+    return _oracle[default_arithmetic]
 
 
 def _vp(a):
@@ -150,10 +162,10 @@ class OracleScene:
 
 
 def oracle_render(scene, width, height, ray_max_depth, n_iterations, first_iteration=0, sampler=S.JITTERED,
-                  n_threads=8, into=None, super_sampling=False, image_v=None, russian_roulette=False):
+                  n_threads=8, into=None, super_sampling=False, image_v=None, russian_roulette=False, default_arithmetic=False):
     """Returns (imageColor[H,W,4], imageRayNb[H,W], (depths, bbx, tri), totals dict).  `into` = a previous
     result tuple to keep accumulating into (iteration ranges must then be rendered in order)."""
-    lib = oracle()
+    lib = oracle(default_arithmetic)
     osc = OracleScene(scene, width, height, ray_max_depth, sampler, super_sampling, russian_roulette)
     if into is None:
         color = np.zeros((height, width, 4), np.float32)

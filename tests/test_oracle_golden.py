@@ -104,6 +104,43 @@ def test_oracle_equals_the_reference_strict_build(case, scene_factory):
     assert len(bad) == 0, f"{len(bad)} channel values differ from the reference's strict build, first at {bad[:5].tolist()}"
 
 
+@pytest.mark.parametrize("case", list(cases.CASES))
+def test_oracle_default_build_equals_the_reference_default_build(case, scene_factory):
+    """Bit for bit: the oracle's DEFAULT-ARITHMETIC build (oracle/build/libpt_oracle_da.so: fused a*b+c where the OpenCL front
+    end contracts, division through v_rcp_f32 and square roots through v_sqrt_f32 from the tables measured on the MI355X)
+    against the committed outputs of the reference kernel as its own build line compiles it (fixtures `it0_8_*`, `it8_8_*`,
+    `it0_1_color`: images, sample counts and the three histograms of two 8-iteration shards and of iteration 0 alone)."""
+    fx = np.load(os.path.join(GOLDEN, f"ref_{case}.npz"))
+    name, sampler, w, h, d = cases.CASES[case]
+    if name == "tris1m" and os.environ.get("PTMI_SKIP_SLOW"):
+        pytest.skip("slow")
+    sc = scene_factory(name, w, h)
+    one, _, _, _ = O.oracle_render(sc, w, h, d, 1, sampler=sampler, default_arithmetic=True)
+    assert np.array_equal(one.view(np.uint32), fx["it0_1_color"].view(np.uint32))
+    for first, n in cases.FIXTURE_RANGES:
+        tag = f"it{first}_{n}"
+        color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, n, first_iteration=first, sampler=sampler, default_arithmetic=True)
+        assert np.array_equal(count, fx[tag + "_count"]) and np.array_equal(dep, fx[tag + "_depths"])
+        assert np.array_equal(bbx.astype(np.int64), _expand(fx[tag + "_bbx_idx"], fx[tag + "_bbx_val"]))
+        assert np.array_equal(tri.astype(np.int64), _expand(fx[tag + "_tri_idx"], fx[tag + "_tri_val"]))
+        bad = np.argwhere(color.view(np.uint32) != fx[tag + "_color"].view(np.uint32))
+        assert len(bad) == 0, f"{tag}: {len(bad)} channel values differ from the reference's default build, first at {bad[:5].tolist()}"
+
+
+def test_oracle_default_build_equals_the_reference_default_build_feature_by_feature(built):
+    """... and every material branch, light type, texture path and the cube-map sky in that arithmetic (`<feature>_default`
+    digests of tests/golden/ref_feat_64x64_d8_features.npz)."""
+    from opencl_pathtracer_amd import scenes, bvh_create
+    fcase, w, h, d = cases.FEATURE_CASE
+    fx = np.load(os.path.join(GOLDEN, f"ref_{fcase}_features.npz"))
+    if scenes.FEATURES[0] + "_default" not in fx:
+        pytest.skip("feature fixture predates the default-build digests")
+    for feature in scenes.FEATURES:
+        sc = bvh_create(scenes.build("feat_" + feature, w, h))
+        color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.FEATURE_SPP, default_arithmetic=True)
+        assert cases.result_digest(color, count, dep, bbx, tri) == str(fx[feature + "_default"]), feature
+
+
 def test_oracle_equals_the_reference_strict_build_feature_by_feature(built):
     """Every material branch, light type, texture path and the cube-map sky, one per scene: SHA-256 of the oracle's result
     equals the digest of the reference's strict build (tests/golden/ref_feat_64x64_d8_features.npz)."""

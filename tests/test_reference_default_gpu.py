@@ -1,0 +1,149 @@
+"""The integrator in the arithmetic of the build the reference's OWN build line produces (GPU).
+
+`OpenCL_BuildOptions` (Controleur/PathTracer_OpenCL.cpp:292-314) passes no floating-point option, so the reference runs its
+OpenCL compiler's DEFAULT arithmetic: `a * b + c` written in one expression is one fused multiply-add, a division goes
+through v_rcp_f32 of the divisor's mantissa, a square root is v_sqrt_f32.  `PTMI_FLAG_DEFAULT_ARITHMETIC` selects a build
+of the integrator's device code that restates exactly that (csrc/ptmi_device.hpp), and the oracle has the same second
+build (oracle/build/libpt_oracle_da.so).  Here:
+
+  * operator level: the product's fdiv / frcp / constant-divisor fdiv / fsqrt / length / mad == what the image's OpenCL
+    compiler emits for `/`, `sqrt`, `length`, `a*b+c` (oracle/arith_probe.cl, our own source compiled with the reference's
+    flags) == the oracle's table-driven host emulation, on millions of operands;
+  * kernel level: images, sample counts and the three histograms == the reference kernel's default build
+    (oracle/_ref/ref_kernel_*.hsaco: unmodified source, the reference's own options), bit for bit, on the seven parity
+    cases, the twelve one-feature scenes and at BASELINE's full sizes;
+  * oracle level: HIP (both kernels) == the oracle's default-arithmetic build, bit for bit.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_ffi as O
+from opencl_pathtracer_amd import render_scene, scenes, bvh_create, backend, structs as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROBE = os.path.join(ROOT, "oracle", "build", "libdevice_math_probe.so")
+PROBE_CL = os.path.join(ROOT, "oracle", "build", "arith_probe.hsaco")
+DA = backend.FLAG_DEFAULT_ARITHMETIC
+OPS = ["a / b", "1.0f / a", "a / 255.f", "a / 3.f", "a / 1.55f", "a / 1920", "a / 90", "sqrt(a)", "length(a, b, a/2, 0)", "a * b + 1"]
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _same_bits(x, y):
+    """bit equality, any NaN equal to any NaN"""
+    return (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
+
+
+def test_default_arithmetic_operators():
+    if not (os.path.exists(PROBE) and os.path.exists(PROBE_CL)):
+        pytest.fail("oracle/build/libdevice_math_probe.so / arith_probe.hsaco not built (make -C oracle probe)")
+    rs = np.random.RandomState(5)
+    n_rand = 1 << 20
+    def wide(n):
+        return (rs.choice([-1.0, 1.0], n) * rs.uniform(1, 2, n) * np.exp2(rs.randint(-149, 128, n).astype(np.float64))).astype(np.float32)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 2.0, 0.5, 1e-45, -1e-45, 1.1754942e-38, 1.1754944e-38,
+                        3.4028235e38, 255.0, 3.0, 1.55, 1e-39, 5e-42], np.float32)
+    sa, sb = np.meshgrid(special, special)
+    a = np.concatenate([wide(n_rand), rs.uniform(-2, 2, n_rand).astype(np.float32), rs.uniform(0, 1, n_rand).astype(np.float32), sa.ravel()])
+    b = np.concatenate([wide(n_rand), rs.uniform(-2, 2, n_rand).astype(np.float32), rs.uniform(0.5, 4, n_rand).astype(np.float32), sb.ravel()])
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    n = len(a)
+    product, compiler, hw = np.empty((10, n), np.float32), np.empty((10, n), np.float32), np.empty((2, n), np.float32)
+    lib = C.CDLL(PROBE)
+    lib.device_arith_probe.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.device_arith_probe(PROBE_CL.encode(), _vp(a), _vp(b), n, _vp(product), _vp(compiler), _vp(hw)) == 0
+    for k, op in enumerate(OPS):
+        bad = np.flatnonzero(~_same_bits(product[k], compiler[k]))
+        assert len(bad) == 0, (f"{op}: the product's default-arithmetic operator differs from the OpenCL compiler's on {len(bad)} of {n} "
+                               f"operands, e.g. a={a[bad[0]]!r} b={b[bad[0]]!r}: {product[k][bad[0]]!r} vs {compiler[k][bad[0]]!r}")
+    # ... and the oracle's host emulation (tables of v_rcp_f32 / v_sqrt_f32 measured on this GPU) gives the same bits
+    ol = O.oracle(default_arithmetic=True)
+    host = np.empty((10, n), np.float32)
+    ol.pto_arith_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    ol.pto_arith_probe(_vp(a), _vp(b), n, _vp(host))
+    for k, op in enumerate(OPS):
+        bad = np.flatnonzero(~_same_bits(host[k], compiler[k]))
+        assert len(bad) == 0, (f"{op}: the oracle's default-arithmetic build differs from the OpenCL compiler's on {len(bad)} of {n} "
+                               f"operands, e.g. a={a[bad[0]]!r} b={b[bad[0]]!r}: {host[k][bad[0]]!r} vs {compiler[k][bad[0]]!r}")
+    # the strict build of the oracle is something else: the two arithmetics are really different
+    strict = np.empty((10, n), np.float32)
+    os_ = O.oracle(default_arithmetic=False)
+    os_.pto_arith_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    os_.pto_arith_probe(_vp(a), _vp(b), n, _vp(strict))
+    assert (~_same_bits(strict[0], host[0])).mean() > 0.01 and (~_same_bits(strict[7], host[7])).mean() > 0.01
+
+
+def _assert_equal_to_reference(ours, ref, what):
+    color, count, (dep, bbx, tri), _ = ours
+    r_color, r_count, (r_dep, r_bbx, r_tri), _ = ref
+    assert np.array_equal(count, r_count), f"{what}: sample counts differ"
+    assert np.array_equal(dep, r_dep) and np.array_equal(bbx, r_bbx) and np.array_equal(tri, r_tri), f"{what}: histograms differ"
+    bad = np.argwhere(color.view(np.uint32) != r_color.view(np.uint32))
+    assert len(bad) == 0, f"{what}: {len(bad)} channel values differ from the reference's default build, first at {bad[:5].tolist()}"
+
+
+@pytest.mark.parametrize("case", list(cases.CASES))
+def test_bit_exact_vs_reference_default_build(case, scene_factory):
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+    name, sampler, w, h, d = cases.CASES[case]
+    sc = scene_factory(name, w, h)
+    spp = 16
+    ref = O.ref_gpu_render(case, sc, w, h, d, spp)
+    _assert_equal_to_reference(render_scene(sc, w, h, d, spp, sampler=sampler, flags=DA), ref, case)
+    if case in ("cornell_64x48_d4", "matmix_96x96_d8", "tris20k_96x64_d6"):  # the one-path-per-lane kernel too
+        _assert_equal_to_reference(render_scene(sc, w, h, d, spp, sampler=sampler, flags=DA | backend.FLAG_MEGAKERNEL), ref, case + " (megakernel)")
+
+
+@pytest.mark.parametrize("feature", scenes.FEATURES)
+def test_every_feature_bit_exact_vs_reference_default_build(feature):
+    """One kernel feature per scene (materials, textures, light types, sky, two-sided / fallback normals), 256 spp = 1M paths
+    each: all five material branches, every light type, every division / square root / contraction site of the kernel."""
+    case, w, h, d = "feat_64x64_d8", 64, 64, 8
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present")
+    sc = bvh_create(scenes.build("feat_" + feature, w, h))
+    ref = O.ref_gpu_render(case, sc, w, h, d, 256)
+    _assert_equal_to_reference(render_scene(sc, w, h, d, 256, flags=DA), ref, feature)
+
+
+FULL_SIZE = {"tris1m_1920x1080_d10": ("tris1m", S.JITTERED, 1920, 1080, 10, 2),   # BASELINE configs[2]: the bench workload
+             "cornell_1920x1080_d8": ("cornell", S.JITTERED, 1920, 1080, 8, 4)}     # BASELINE configs[1]
+
+
+@pytest.mark.parametrize("case", list(FULL_SIZE))
+def test_full_size_bit_exact_vs_reference_default_build(case):
+    """BASELINE's own image size, scene and ray depth: all 2 M pixels, the sample counts and the three histograms equal the
+    reference kernel as its own build line compiles it, run beside the integrator on this GPU."""
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+    name, sampler, w, h, d, spp = FULL_SIZE[case]
+    sc = bvh_create(scenes.build(name, w, h))
+    ref = O.ref_gpu_render(case, sc, w, h, d, spp)
+    _assert_equal_to_reference(render_scene(sc, w, h, d, spp, sampler=sampler, flags=DA), ref, case)
+
+
+@pytest.mark.parametrize("case", ["cornell_64x48_d4", "cornell_64x48_d4_uni", "matmix_96x96_d8", "tris20k_96x64_d6"])
+def test_default_arithmetic_hip_equals_oracle(case, scene_factory):
+    """HIP (wavefront and one-path-per-lane kernels) == the oracle's default-arithmetic build, bit for bit - the oracle's
+    second build is pinned to the reference's default build through the integrator and directly by
+    tests/test_oracle_golden.py (committed outputs of that build)."""
+    name, sampler, w, h, d = cases.CASES[case]
+    sc = scene_factory(name, w, h)
+    spp = 8
+    o_color, o_count, (o_dep, o_bbx, o_tri), totals = O.oracle_render(sc, w, h, d, spp, sampler=sampler, default_arithmetic=True)
+    for flags in (DA, DA | backend.FLAG_MEGAKERNEL):
+        color, count, (dep, bbx, tri), counters = render_scene(sc, w, h, d, spp, sampler=sampler, flags=flags)
+        assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)), f"flags {flags}"
+        assert np.array_equal(count, o_count) and np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
+        assert counters == totals
+    # and the two arithmetics are really different renders
+    s_color, _, _, _ = render_scene(sc, w, h, d, spp, sampler=sampler)
+    assert not np.array_equal(s_color.view(np.uint32), o_color.view(np.uint32))
