@@ -14,11 +14,21 @@ on a full scene replica with no data-path exchange, and ONE RCCL reduce of the f
 onto rank 0 closes the timed region.  Weak scaling by default (every rank renders --spp-per-step ids per step);
 --strong / --total-spp fix the job instead (BASELINE configs[3]: 4096 spp split over the ranks).
 
-Prints ONE JSON line on rank 0.  Extra objects: "roofline" (HBM on SURVEY 8d's algorithmic bytes, plus the measured
-memory-side traffic and the ceilings that actually bind, from the PMC passes committed under profiles/), at N=1
-"cpu_baseline" (the CPU oracle = scalar port of the reference kernel, timed on the host cores on a bounded sample)
-and "boundary" (the same integrator driven the way the reference drives its backend: one image per launch, a
-readback and a callback after every image, OpenCL.cpp:76-107).
+Arithmetic: --arithmetic default (the default) renders in the arithmetic of the kernel the reference's own build line
+produces (PTMI_FLAG_DEFAULT_ARITHMETIC: images equal that kernel's bit for bit, tests/test_reference_default_gpu.py);
+--arithmetic strict is the other bit-exact mode (the reference's strict build).
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  "roofline"          the ceiling that BINDS this kernel (bound / frac <= 1), from the PMC passes of this command committed
+                      under profiles/ (used only if they were taken on this very kernel source) and this run's launch time
+                      (HIP events on the kernel's stream); beside it "hbm_measured" (memory-side traffic / time) and
+                      "hbm_algorithmic_model" (SURVEY 8d's algorithmic bytes / time: what the traversal must READ, most of it
+                      from the caches - a model, not a ceiling, and may exceed the HBM peak);
+  at N=1 "reference_kernel"  the reference's own Kernel_Main (unmodified source, its own build options, oracle/_ref/*.hsaco)
+                      timed on this GPU in this run, and the ratios to it (-> vs_baseline);
+         "cpu_baseline"      the CPU oracle = scalar port of the reference kernel on the host cores, bounded sample;
+         "boundary"          the integrator driven the way the reference drives its backend: one image per launch, a
+                             readback and a callback after every image (OpenCL.cpp:76-107).
 """
 import argparse
 import json
@@ -62,6 +72,10 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--kernel", choices=["wavefront", "megakernel"], default="wavefront")
+    ap.add_argument("--arithmetic", choices=["default", "strict"], default="default",
+                    help="default = the arithmetic of the reference's own build (OpenCL default: what its build line produces); "
+                         "strict = its -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt build.  Both bit-exact modes")
+    ap.add_argument("--no-reference-kernel", action="store_true", help="skip timing the reference's own kernel beside (N=1 only)")
     ap.add_argument("--scheduler-stats", action="store_true", help="also report wave-scheduler statistics (costs ~1 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-boundary", action="store_true", help="skip the reference-style per-image loop (N=1 only)")
@@ -78,7 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
     import opencl_pathtracer_amd as pt
-    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS, FLAG_MEGAKERNEL, FLAG_SCHEDULER_STATS
+    from opencl_pathtracer_amd.backend import FLAG_NO_HISTOGRAMS, FLAG_MEGAKERNEL, FLAG_SCHEDULER_STATS, FLAG_DEFAULT_ARITHMETIC
     from opencl_pathtracer_amd.distributed import FusedAccumulators, shard_iterations
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,7 +121,7 @@ def main():
     t_scene = time.time() - t0
 
     flags = ((FLAG_NO_HISTOGRAMS if args.no_histograms else 0) | (FLAG_MEGAKERNEL if args.kernel == "megakernel" else 0)
-             | (FLAG_SCHEDULER_STATS if args.scheduler_stats else 0))
+             | (FLAG_SCHEDULER_STATS if args.scheduler_stats else 0) | (FLAG_DEFAULT_ARITHMETIC if args.arithmetic == "default" else 0))
     be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=local_rank, flags=flags)
     be.initialize_memory(scene)
     fb = FusedAccumulators(W, H, device)
@@ -186,21 +200,30 @@ def main():
         avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = b_alg / max(launches, 1) / avg_launch_s / 1e9
         records_per_launch = (delta["box_tests"] / 2 + delta["triangle_tests"]) / max(launches, 1)
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+        model = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+                 "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
+                 "note": "SURVEY 8d ALGORITHMIC bytes (32 B per box test, 48 B per triangle test, 96 B per surface hit, 40 B per "
+                         "pixel flush) / launch time: what the traversal must read, nearly all of it served by the L1s / L2s / "
+                         "Infinity Cache (hbm_measured is what reaches memory) - a model of the work, NOT a ceiling of this kernel"}
+        roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "kernel": "render_wavefront_kernel" if args.kernel == "wavefront" else "render_kernel",
+                "arithmetic": args.arithmetic,
                 "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
-                "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
                 "box_tests_per_path": delta["box_tests"] / max(delta["paths"], 1),
                 "triangle_tests_per_path": delta["triangle_tests"] / max(delta["paths"], 1),
                 "record_fetches_per_s": records_per_launch / avg_launch_s,
-                "note": "achieved = SURVEY 8d ALGORITHMIC bytes (a model of what the traversal must read: 32 B per box test, 48 B per "
-                        "triangle test ...) / launch time measured with HIP events on the kernel's stream.  Where the record array fits "
-                        "the L2s + Infinity Cache this stream never reaches HBM and the figure may exceed the HBM peak: 'hbm_measured' "
-                        "is the memory-side traffic of the PMC passes and 'binding' the ceilings the kernel actually runs into"}
+                "hbm_algorithmic_model": model}
         pmc = committed_pmc(args, W, H, D, B)
         if pmc:
             roof.update(binding_ceilings(pmc, avg_launch_s, records_per_launch))
+        else:
+            # no PMC passes of THIS kernel source on this workload: the one ceiling that can be priced from this run alone -
+            # 64-byte record gathers against what the chip's L1s deliver for that access pattern (tools/microbench/record_fetch)
+            rate = records_per_launch / avg_launch_s
+            roof.update({"bound": "l1_record_gathers", "achieved": rate / 1e9, "peak": L1_ACCESS_RATE / 4 / 1e9, "unit": "G records/s",
+                         "frac": min(1.0, rate / (L1_ACCESS_RATE / 4)),
+                         "note": "no committed PMC passes match this kernel source + workload (profiles/r03_pmc_*.json): priced on the "
+                                 "record-gather ceiling of tools/microbench/record_fetch only; run tools/profile_round.sh"})
         out = {
             "metric": "Msamples/s (paths x bounces) at 1920x1080",
             "value": total["segments"] / elapsed / 1e6,
@@ -208,6 +231,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "arithmetic": args.arithmetic,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload_name(args.scene)}: {len(scene.triangulation)} triangles "
                                    f"({len(scene.bvh)} BVH nodes, depth {scene.bvhMaxDepth}), {W}x{H}, "
@@ -230,8 +254,15 @@ def main():
             out["wave_scheduler"]["wave_time_in_path_logic"] = round(sched["cycles_path"] / max(sched["cycles_loop"], 1), 3)
         if world == 1 and not args.no_boundary:
             out["boundary"] = boundary_loop(pt, scene, W, H, D, local_rank, flags, out["value"])
+        if world == 1 and not args.no_reference_kernel and args.kernel == "wavefront":
+            ref = reference_kernel_leg(pt, scene, args, W, H, D, local_rank, flags, out["Mpaths/s"])
+            if ref:
+                out["reference_kernel"] = ref
+                out["vs_baseline"] = ref["ratio_at_the_integrators_launch_size"]
+                out["vs_baseline_note"] = ("value / the reference's own OpenCL kernel (unmodified source, its own build options, 8x8 "
+                                           "work-groups) timed on this GPU in this run on the same workload; BASELINE.md holds no published number")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, D, args.cpu_rows, args.cpu_spp)
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, D, args.cpu_rows, args.cpu_spp, args.arithmetic == "default")
         print(json.dumps(out), flush=True)
 
     if world > 1:
@@ -240,51 +271,67 @@ def main():
 
 def workload_name(scene):
     return {"tris1m": "BASELINE configs[2]: synthetic random-triangle scene (numpy MT19937 seed 12345)",
-            "tris4m": "HBM-regime variant of configs[2]: 4M random triangles, 427 MB of records (> the 256 MiB Infinity Cache)",
+            "tris4m": "larger variant of configs[2]: 4M random triangles, 427 MB of records (> the 256 MiB Infinity Cache; still not "
+                      "HBM-bound: measured memory-side traffic is ~0.2 % of the HBM peak)",
             "cornell": "BASELINE configs[0]/[1]: Cornell box (point light under a lamp quad)",
             "matmix": "BASELINE configs[4] stand-in: textured multi-material scene (no Maya assets exist)"}.get(scene, scene)
 
 
+def kernel_source_digest():
+    """SHA-256 over the integrator's device sources: PMC passes are only quoted for the kernel they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "opencl_pathtracer_amd", "csrc")
+    for f in ("kernel_wavefront.hip", "ptmi_device.hpp", "ptmi_shading.hpp", "ptmi_internal.h"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ptmi_detmath.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def committed_pmc(args, W, H, D, B):
     """Per-launch means of the rocprofv3 --pmc passes of THIS command line (tools/profile_round.sh: one counter group per
-    run, summarised by tools/summarize_pmc.py), committed as profiles/r02_pmc_<scene>.json.  bench.py itself cannot read
-    PMC counters; the file is only used for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.scene}.json")
+    run, summarised by tools/summarize_pmc.py), committed as profiles/r03_pmc_<scene>_<arithmetic>.json.  bench.py itself
+    cannot read PMC counters; the file is used only for the configuration AND the kernel source it was measured on."""
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.scene}_{args.arithmetic}.json")
     if not os.path.exists(path) or (W, H, D, args.kernel) != (1920, 1080, 10, "wavefront"):
         return None
     pmc = json.load(open(path))
     if pmc.get("_spp_per_launch") != min(B, 32):  # counters are per launch: only comparable at the same launch size
+        return None
+    if pmc.get("_kernel_source_digest") != kernel_source_digest():
         return None
     pmc["_path"] = os.path.relpath(path, ROOT)
     return pmc
 
 
 def binding_ceilings(pmc, launch_s, records_per_launch):
-    """traffic = memory-side bytes per launch (FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes for
-    16-byte-per-lane loads, plus WRITE_SIZE), and the ceilings the kernel runs against, each as a fraction <= 1: VALU issue,
-    the scalar unit, L2 request bandwidth, and the L1s' access and line-fill rates."""
+    """The units this kernel loads, each as achieved / peak <= 1, from the committed PMC passes (per-launch means) and THIS
+    run's launch time; the largest is the roofline's `bound`.  traffic = memory-side bytes per launch (FETCH_SIZE doubled as
+    the gfx950 note of MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads, plus WRITE_SIZE)."""
     v = lambda k: pmc[k]["per_launch_mean"] if k in pmc else None
-    out = {"traffic_source": pmc["_path"] + " (PMC passes of this command, committed; not measured in this run)"}
+    out = {"traffic_source": pmc["_path"] + " (PMC passes of this command on this kernel source, committed; not measured in this run)"}
     if v("FETCH_SIZE") is not None and v("WRITE_SIZE") is not None:
         traffic = (2.0 * v("FETCH_SIZE") + v("WRITE_SIZE")) * 1024.0
         out["traffic"] = traffic
         out["hbm_measured"] = {"achieved": traffic / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": traffic / launch_s / 1e9 / HBM_PEAK_GBS}
+    # cycles of the launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs; else the 2.4 GHz maximum clock
+    cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
     binding = {}
-    if v("SQ_INSTS_VALU") is not None:
-        # cycles of the launch from GRBM_GUI_ACTIVE (summed over the 8 XCDs) where collected, else at the 2.4 GHz maximum
-        # clock.  What a wave64 VALU instruction costs its SIMD, measured (tools/microbench/pk_rate.hip): 2 cycles for plain
-        # 32-bit operations (v_fma_f32, v_mul_f32, v_add_u32, v_mov_b32), 4 for packed fp32, 64-bit integer, three-operand
-        # min / max, compares into SGPRs and v_mbcnt, 8 for v_rcp_f32.  No counter of this chip separates the classes, so
-        # `frac` prices every instruction at 4 cycles - an UPPER bound of how busy the VALUs are - and `frac_if_all_2_cycles`
-        # is the lower bound.
-        cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
-        binding["valu_issue"] = {"achieved": v("SQ_INSTS_VALU") * 4.0 / N_SIMD, "peak": cycles, "unit": "cycles per SIMD per launch",
-                                 "frac": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles,
-                                 "frac_if_all_2_cycles": v("SQ_INSTS_VALU") * 2.0 / N_SIMD / cycles}
+    if v("SQ_ACTIVE_INST_VALU") is not None:
+        # MEASURED busy time of the vector ALUs: SQ_ACTIVE_INST_VALU counts, in quad-cycles and summed over all waves, the
+        # time waves spend executing VALU instructions (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* are quad-cycles); a SIMD runs one
+        # VALU instruction at a time, so x 4 / 1024 SIMDs / launch cycles is the fraction of time the VALUs are busy (rocprof's
+        # VALUBusy).  One number: every instruction enters at what it really cost (2, 4 or 8 cycles; tools/microbench/pk_rate.hip).
+        busy = v("SQ_ACTIVE_INST_VALU") * 4.0 / N_SIMD
+        binding["valu_busy"] = {"achieved": busy, "peak": cycles, "unit": "busy cycles per SIMD per launch", "frac": busy / cycles}
+        if v("SQ_INSTS_VALU") is not None:
+            binding["valu_busy"]["cycles_per_instruction"] = v("SQ_ACTIVE_INST_VALU") * 4.0 / v("SQ_INSTS_VALU")
+    elif v("SQ_INSTS_VALU") is not None:
+        binding["valu_issue_range"] = {"frac_if_all_4_cycles": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles,
+                                       "frac_if_all_2_cycles": v("SQ_INSTS_VALU") * 2.0 / N_SIMD / cycles}
     if v("SQ_INSTS_SALU") is not None:
         # one scalar unit per CU (256 of them), one instruction per cycle at best
-        cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
         binding["scalar_unit"] = {"achieved": v("SQ_INSTS_SALU") / 256.0, "peak": cycles, "unit": "instructions per CU per launch",
                                   "frac": v("SQ_INSTS_SALU") / 256.0 / cycles}
     if v("TCC_HIT_sum") is not None and v("TCC_MISS_sum") is not None:
@@ -306,10 +353,55 @@ def binding_ceilings(pmc, launch_s, records_per_launch):
         binding["wave_cycles"] = {"waiting": v("SQ_WAIT_ANY") / v("SQ_WAVE_CYCLES"),
                                   "issue_stalled": (v("SQ_WAIT_INST_ANY") or 0.0) / v("SQ_WAVE_CYCLES"),
                                   "issuing": (v("SQ_ACTIVE_INST_ANY") or 0.0) / v("SQ_WAVE_CYCLES")}
-    if binding:
-        binding["binds"] = max((k for k in binding if "frac" in binding[k]), key=lambda k: binding[k]["frac"])
+    ranked = [k for k in binding if "frac" in binding[k]]
+    if ranked:
+        top = max(ranked, key=lambda k: binding[k]["frac"])
+        binding["binds"] = top
+        out.update({"bound": top, "achieved": binding[top]["achieved"], "peak": binding[top]["peak"], "unit": binding[top]["unit"],
+                    "frac": binding[top]["frac"]})
         out["binding"] = binding
     return out
+
+
+def reference_kernel_leg(pt, scene, args, W, H, D, device, flags, batched_mpaths):
+    """north_star: ">= 10x the repo's OpenCL kernel Msamples/s on 1 x MI355X" - the denominator, measured here: the
+    reference's own Kernel_Main (oracle/_ref/ref_kernel_<scene>_<W>x<H>_d<D>.hsaco: unmodified source, the options of its
+    own build line, compiled by the image's clang for gfx950) on the same scene, launched as OpenCL.cpp:76-107 launches it -
+    one W x H launch per iteration, a wait after each - but with 8x8 work-groups (its own 1x1, OpenCL.cpp:72, would idle 63 of
+    64 lanes), 2 iterations, HIP events around each launch.  Beside it this integrator made to launch the same way (one
+    iteration per launch, a wait after each).  After the timed region; a baseline, never part of `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import oracle_ffi as O
+    except Exception as e:  # noqa: BLE001
+        return {"skipped": f"tests/oracle_ffi.py not importable: {e}"}
+    case = f"{args.scene}_{W}x{H}_d{D}"
+    if not O.have_ref_kernel(case):
+        return {"skipped": f"oracle/_ref/ref_kernel_{case}.hsaco not present (built by `make -C oracle ref` where the reference tree exists)"}
+    n_it = 2
+    O.ref_gpu_render(case, scene, W, H, D, 1, first_iteration=7)  # warm-up: module load, clocks
+    _, _, _, ms = O.ref_gpu_render(case, scene, W, H, D, n_it)
+    ref_mpaths = W * H * n_it / ms / 1e3
+    # the integrator launched the same way: one iteration per launch and a wait after every launch
+    be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=device, flags=flags)
+    be.initialize_memory(scene)
+    be.render(100, 1)
+    be.synchronize()
+    n_own = 8
+    t0 = time.perf_counter()
+    for k in range(n_own):
+        be.render(k, 1)
+        be.synchronize()
+    dt = time.perf_counter() - t0
+    be.release()
+    own_mpaths = W * H * n_own / dt / 1e6
+    return {"Mpaths/s": ref_mpaths, "iterations": n_it, "work_group": "8x8", "kernel_ms_per_iteration": ms / n_it,
+            "code_object": f"oracle/_ref/ref_kernel_{case}.hsaco (default build: the reference's own options)",
+            "integrator_one_iteration_per_launch_Mpaths/s": own_mpaths,
+            "ratio_at_equal_launch_counts": own_mpaths / ref_mpaths,
+            "ratio_at_the_integrators_launch_size": batched_mpaths / ref_mpaths,
+            "note": "same scene, same samples (in --arithmetic default the two kernels' images are equal bit for bit), same GPU, same "
+                    "run; paths/s ratio = samples/s ratio (same segments per path)"}
 
 
 def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
@@ -382,9 +474,10 @@ def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
     return res
 
 
-def cpu_baseline(scene, W, H, D, rows, n_iter):
-    """The CPU oracle (scalar C port of the reference kernel, test infrastructure) timed on the host cores
-    on a bounded sample of the SAME workload: iterations 0..n-1 of the first `rows` image rows, all host threads."""
+def cpu_baseline(scene, W, H, D, rows, n_iter, default_arithmetic=False):
+    """The CPU oracle (scalar C port of the reference kernel, test infrastructure; its build in the arithmetic the bench
+    renders in) timed on the host cores on a bounded sample of the SAME workload: iterations 0..n-1 of the first `rows` image
+    rows, all host threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
     cores = host_cores()
@@ -392,7 +485,7 @@ def cpu_baseline(scene, W, H, D, rows, n_iter):
         # a short probe gives this scene's rate; then aim at ~15 s of CPU work, whole images first
         probe_rows = max(cores, min(H, 4 * cores))
         t0 = time.perf_counter()
-        _, _, _, tot = oracle_rows(O, scene, W, H, D, probe_rows, cores, 1)
+        _, _, _, tot = oracle_rows(O, scene, W, H, D, probe_rows, cores, 1, default_arithmetic)
         rate = tot["paths"] / max(time.perf_counter() - t0, 1e-6)
         target_paths = 15.0 * rate
         if n_iter <= 0:
@@ -400,9 +493,10 @@ def cpu_baseline(scene, W, H, D, rows, n_iter):
         if rows <= 0:
             rows = H if target_paths >= W * H else max(cores, int(target_paths // W))
     t0 = time.perf_counter()
-    _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores, n_iter)
+    _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores, n_iter, default_arithmetic)
     dt = time.perf_counter() - t0
     return {"value": totals["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "arithmetic": "default" if default_arithmetic else "strict",
             "sample": f"iterations 0..{n_iter - 1} of rows 0..{rows - 1} of the {W}x{H} image ({n_iter * rows * W} paths, "
                       f"{totals['segments']} segments) in {dt:.1f} s on {cores} threads",
             "Mpaths/s": totals["paths"] / dt / 1e6}
@@ -420,13 +514,13 @@ def host_cores():
     return n
 
 
-def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1):
+def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1, default_arithmetic=False):
     """Render iterations 0..n_iter-1 for the first `rows` rows by running the oracle on a W x rows 'image' whose
     camera rays equal those of rows 0..rows-1 of the full image: seed and jitter depend on (x, y, W, H),
     so the full-size H is kept and only the row loop is cut short."""
     import ctypes as C
     import numpy as np
-    lib = O.oracle()
+    lib = O.oracle(default_arithmetic)
     osc = O.OracleScene(scene, W, H, D)
     color = np.zeros((H, W, 4), np.float32)
     count = np.zeros((H, W), np.float32)

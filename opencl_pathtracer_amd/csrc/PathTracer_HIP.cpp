@@ -43,6 +43,7 @@
 //   PTMI_IMAGES_PER_LAUNCH = images rendered per step AND per callback (default 1 = the reference's count of callbacks)
 //   PTMI_LOOKAHEAD = steps queued ahead of the one being read back when PTMI_BURST is 1 (default max(2, devices); 0 = the
 //                    reference's launch / wait / read / callback sequence)
+//   PTMI_STRICT_ARITHMETIC = 1: the strict arithmetic instead of the reference's default-build arithmetic (ptmi.h, PTMI_FLAG_DEFAULT_ARITHMETIC)
 //   PTMI_LOG = 1 (or globalVars.printLogInfos, the reference's -D LOG_INFO switch, OpenCL.cpp:310): one line per step
 //              on stderr with the iteration range and the three timers
 #ifdef PTMI_USE_REFERENCE_HEADERS
@@ -132,7 +133,10 @@ void OpenCL_SetupContext(GlobalVars& globalVars, Sampler sampler)
     cfg.sampler = sampler == RANDOM ? PTMI_SAMPLER_RANDOM : (sampler == UNIFORM ? PTMI_SAMPLER_UNIFORM : PTMI_SAMPLER_JITTERED);
     cfg.super_sampling = globalVars.superSampling ? 1u : 0u;
     g_staged = sampler != RANDOM && !globalVars.superSampling;
-    cfg.flags = 0;
+    // The arithmetic of the kernel OpenCL_BuildOptions would have produced (it passes no floating-point option: OpenCL default
+    // arithmetic), so that a caller of the reference API gets the reference's images bit for bit; PTMI_STRICT_ARITHMETIC=1
+    // selects the other bit-exact mode (the build the same source gives with correctly rounded operations).
+    cfg.flags = env_uint("PTMI_STRICT_ARITHMETIC", 0) ? 0u : PTMI_FLAG_DEFAULT_ARITHMETIC;
     const int rc = ptmi_setup_context(&g_ctx, &cfg);
     if (rc) fail("OpenCL_SetupContext", rc);
 }

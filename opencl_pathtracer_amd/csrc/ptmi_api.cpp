@@ -125,6 +125,10 @@ void free_scene_memory(ptmi_ctx* ctx)
 {
     for (DeviceState& d : ctx->dev) {
         (void)hipSetDevice(d.device);
+        // every stream that may still run a kernel or a copy on this memory - the launch streams too: after a failure between a
+        // launch and the main stream's wait for it (render_on_device) a persistent kernel may still be reading the scene
+        for (int i = 0; i < 2; i++)
+            if (d.launch_stream[i]) (void)hipStreamSynchronize(d.launch_stream[i]);
         (void)hipStreamSynchronize(d.stream);
         if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
         for (void* p : d.allocations) (void)hipFree(p);
@@ -135,7 +139,6 @@ void free_scene_memory(ptmi_ctx* ctx)
         d.d_job_counter = nullptr;
         d.d_scene = nullptr;
         for (int i = 0; i < 2; i++) {
-            if (d.launch_stream[i]) (void)hipStreamSynchronize(d.launch_stream[i]);
             if (d.d_stage[i]) (void)hipFree(d.d_stage[i]);
             d.d_stage[i] = nullptr;
             d.stage_busy[i] = false;
@@ -144,6 +147,9 @@ void free_scene_memory(ptmi_ctx* ctx)
         for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++) {
             if (d.d_snapshot[k]) (void)hipFree(d.d_snapshot[k]);
             d.d_snapshot[k] = nullptr;
+            // ... and the event that says the slot is filled: a slot of the NEXT scene is empty until ptmi_snapshot fills it
+            if (d.snapshot_ready[k]) (void)hipEventDestroy(d.snapshot_ready[k]);
+            d.snapshot_ready[k] = nullptr;
         }
         if (d.d_peer_copy) (void)hipFree(d.d_peer_copy);
         d.d_peer_copy = nullptr;

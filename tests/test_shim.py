@@ -89,17 +89,21 @@ def test_shim_reports_errors_as_exceptions(driver, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strict", [False, True])
 @pytest.mark.parametrize("name,w,h,d,sampler,n", [("cornell", 64, 48, 4, S.JITTERED, 5), ("matmix", 96, 96, 8, S.UNIFORM, 3)])
-def test_shim_end_to_end_matches_oracle(name, w, h, d, sampler, n, driver, tmp_path):
+def test_shim_end_to_end_matches_oracle(name, w, h, d, sampler, n, strict, driver, tmp_path):
+    """The shim renders in the arithmetic of the kernel the reference's own build line produces (the oracle's default-arithmetic
+    build) unless PTMI_STRICT_ARITHMETIC=1 asks for the strict one."""
     sc = scenes.build(name, w, h)  # no BVH: the driver calls BVH_Create itself
     scene_file, out_file = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
     dump_scene(scene_file, sc, w, h, d, sampler, n)
-    r = subprocess.run([driver, scene_file, out_file], capture_output=True, text=True)
+    r = subprocess.run([driver, scene_file, out_file], capture_output=True, text=True,
+                       env={**os.environ, **({"PTMI_STRICT_ARITHMETIC": "1"} if strict else {})})
     assert r.returncode == 0, r.stderr
     (callbacks, bvh_size, bvh_depth), color, count, dep, bbx, tri = read_result(out_file, w, h, d)
     ref = bvh_create(scenes.build(name, w, h))
     assert callbacks == n and bvh_size == len(ref.bvh) and bvh_depth == ref.bvhMaxDepth
-    o_color, o_count, (o_dep, o_bbx, o_tri), _ = O.oracle_render(ref, w, h, d, n, sampler=sampler)
+    o_color, o_count, (o_dep, o_bbx, o_tri), _ = O.oracle_render(ref, w, h, d, n, sampler=sampler, default_arithmetic=not strict)
     assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
     assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
 
@@ -140,10 +144,11 @@ def test_reference_orchestration_links_and_reports_a_missing_device(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="oracle/_ref/ref_main_driver not built (needs the reference tree)")
 @pytest.mark.parametrize("env", [{}, {"PTMI_BURST": "4"}, {"PTMI_DEVICES": "0,0", "PTMI_BURST": "1", "PTMI_LOOKAHEAD": "3"},
-                                 {"PTMI_BURST": "1", "PTMI_LOOKAHEAD": "0"}, {"PTMI_DEVICES": "0,0,0"}])
+                                 {"PTMI_BURST": "1", "PTMI_LOOKAHEAD": "0"}, {"PTMI_DEVICES": "0,0,0"}, {"PTMI_STRICT_ARITHMETIC": "1"}])
 def test_reference_orchestration_renders(env, tmp_path):
     """PathTracer_Main -> BVH_Create -> OpenCL_SetupContext / InitializeMemory / RunKernel of the shim -> libptmi -> HIP
-    kernels; the image the reference's window is handed after the last iteration equals the oracle's."""
+    kernels; the image the reference's window is handed after the last iteration equals the oracle's (in the arithmetic of
+    the reference's own build by default, PTMI_STRICT_ARITHMETIC=1: the strict one)."""
     name, w, h, d, n = "cornell", 64, 48, 4, 6
     sc = scenes.build(name, w, h)
     scene_file, out_file = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
@@ -155,7 +160,7 @@ def test_reference_orchestration_renders(env, tmp_path):
     calls, color, count = read_painted(out_file, w, h)
     assert calls == n
     ref = bvh_create(scenes.build(name, w, h))
-    o_color, o_count, _, _ = O.oracle_render(ref, w, h, d, n)
+    o_color, o_count, _, _ = O.oracle_render(ref, w, h, d, n, default_arithmetic=not env.get("PTMI_STRICT_ARITHMETIC"))
     assert np.array_equal(count, o_count)
     if env.get("PTMI_DEVICES"):  # two partial sums: another order of the float additions
         assert np.allclose(color, o_color, rtol=2e-6, atol=1e-6)

@@ -16,6 +16,11 @@ for name, per_dispatch in acc.items():
     out[name] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
 extra = sys.argv[2] if len(sys.argv) > 2 else ""
 out["_spp_per_launch"] = 32  # bench.py's default --spp-per-step = one launch of 32 iterations per step
+# the kernel source these counters were taken on: bench.py quotes them only for that very source (bench.kernel_source_digest)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out["_kernel_source_digest"] = bench.kernel_source_digest()
 out["_note"] = ("rocprofv3 --pmc <one group per run> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
                 "--no-cpu-baseline --no-boundary " + extra + " (32 spp per launch, 1080p); per-launch means of "
                 "render_wavefront_kernel; FETCH_SIZE/WRITE_SIZE in KB; GRBM_GUI_ACTIVE summed over the 8 XCDs")
