@@ -252,6 +252,9 @@ def main():
             tot = sum(sched["trips_" + k] for k in ("node", "triangle", "path"))
             out["wave_scheduler"]["trip_share"] = {k: round(sched["trips_" + k] / tot, 3) for k in ("node", "triangle", "path")}
             out["wave_scheduler"]["wave_time_in_path_logic"] = round(sched["cycles_path"] / max(sched["cycles_loop"], 1), 3)
+            # raw counts per launch (tools/valu_cost_model.py weights the static instruction mix of each trip kind with them)
+            out["wave_scheduler"]["trips_per_launch"] = {k: sched["trips_" + k] / max(launches + args.warmup, 1) for k in ("node", "triangle", "path")}
+            out["wave_scheduler"]["leaf_item_violations"] = sched["leaf_item_violations"]
         if world == 1 and not args.no_boundary:
             out["boundary"] = boundary_loop(pt, scene, W, H, D, local_rank, flags, out["value"])
         if world == 1 and not args.no_reference_kernel and args.kernel == "wavefront":
@@ -301,6 +304,12 @@ def committed_pmc(args, W, H, D, B):
     if pmc.get("_kernel_source_digest") != kernel_source_digest():
         return None
     pmc["_path"] = os.path.relpath(path, ROOT)
+    mpath = os.path.join(ROOT, "profiles", f"r03_valu_cost_model_{args.scene}_{args.arithmetic}.json")
+    if os.path.exists(mpath):
+        model = json.load(open(mpath))
+        if model.get("sources", {}).get("kernel_source_digest") == pmc["_kernel_source_digest"]:
+            model["_path"] = os.path.relpath(mpath, ROOT)
+            pmc["_valu_cost_model"] = model
     return pmc
 
 
@@ -318,18 +327,21 @@ def binding_ceilings(pmc, launch_s, records_per_launch):
     # cycles of the launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs; else the 2.4 GHz maximum clock
     cycles = v("GRBM_GUI_ACTIVE") / 8.0 if v("GRBM_GUI_ACTIVE") else launch_s * 2.4e9
     binding = {}
-    if v("SQ_ACTIVE_INST_VALU") is not None:
-        # MEASURED busy time of the vector ALUs: SQ_ACTIVE_INST_VALU counts, in quad-cycles and summed over all waves, the
-        # time waves spend executing VALU instructions (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* are quad-cycles); a SIMD runs one
-        # VALU instruction at a time, so x 4 / 1024 SIMDs / launch cycles is the fraction of time the VALUs are busy (rocprof's
-        # VALUBusy).  One number: every instruction enters at what it really cost (2, 4 or 8 cycles; tools/microbench/pk_rate.hip).
-        busy = v("SQ_ACTIVE_INST_VALU") * 4.0 / N_SIMD
-        binding["valu_busy"] = {"achieved": busy, "peak": cycles, "unit": "busy cycles per SIMD per launch", "frac": busy / cycles}
-        if v("SQ_INSTS_VALU") is not None:
-            binding["valu_busy"]["cycles_per_instruction"] = v("SQ_ACTIVE_INST_VALU") * 4.0 / v("SQ_INSTS_VALU")
-    elif v("SQ_INSTS_VALU") is not None:
-        binding["valu_issue_range"] = {"frac_if_all_4_cycles": v("SQ_INSTS_VALU") * 4.0 / N_SIMD / cycles,
-                                       "frac_if_all_2_cycles": v("SQ_INSTS_VALU") * 2.0 / N_SIMD / cycles}
+    if v("SQ_INSTS_VALU") is not None:
+        # How busy the vector ALUs are = instructions x what an instruction costs its SIMD / cycles.  The chip has no counter for
+        # the second factor (SQ_ACTIVE_INST_VALU counts quad-cycles, one per instruction), so it comes from the code:
+        # tools/valu_cost_model.py classes every VALU instruction of the three kinds of trip by the cycle costs measured in
+        # tools/microbench/pk_rate.hip (2 / 4 / 8), weights the kinds with the trip counts of --scheduler-stats and checks the
+        # predicted instruction count against SQ_INSTS_VALU.  One number; the all-2 / all-4 range stays beside it.
+        n = v("SQ_INSTS_VALU")
+        entry = {"frac_if_all_2_cycles": n * 2.0 / N_SIMD / cycles, "frac_if_all_4_cycles": n * 4.0 / N_SIMD / cycles}
+        model = pmc.get("_valu_cost_model")
+        if model:
+            mean = model["mean_cycles_per_valu_instruction"]
+            entry.update({"achieved": n * mean / N_SIMD, "peak": cycles, "unit": "VALU issue cycles per SIMD per launch",
+                          "frac": n * mean / N_SIMD / cycles, "mean_cycles_per_instruction": mean,
+                          "model": model["_path"], "model_predicted_over_measured_instructions": model["predicted_over_measured"]})
+        binding["valu_busy"] = entry
     if v("SQ_INSTS_SALU") is not None:
         # one scalar unit per CU (256 of them), one instruction per cycle at best
         binding["scalar_unit"] = {"achieved": v("SQ_INSTS_SALU") / 256.0, "peak": cycles, "unit": "instructions per CU per launch",
@@ -446,10 +458,10 @@ def boundary_loop(pt, scene, W, H, D, device, flags, batched_value):
         queued = 0
         for b in range(n_bursts):
             while queued < n_bursts and queued <= b + 1:
-                be.render_snapshots(first + queued * burst, burst, (queued * burst) % 32)
+                be.render_snapshots(first + queued * burst, burst, (queued * burst) % 64)
                 queued += 1
             for k in range(burst):
-                be.read_snapshot((b * burst + k) % 32, out=out)
+                be.read_snapshot((b * burst + k) % 64, out=out)
                 callback()
         dt = time.perf_counter() - t0
         c1 = be.counters()

@@ -30,9 +30,9 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 2
+#define PTMI_ABI_VERSION 3 /* 3: PTMI_FLAG_DEFAULT_ARITHMETIC, ptmi_scheduler_stats::leaf_item_violations */
 #define PTMI_MAX_DEVICES 16       /* devices that can share one render */
-#define PTMI_MAX_SNAPSHOT_SLOTS 33 /* ptmi_snapshot ring: slots 0..31 are the caller's, the last one the library's own */
+#define PTMI_MAX_SNAPSHOT_SLOTS 65 /* ptmi_snapshot ring: slots 0..63 are the caller's, the last one the library's own */
 
 typedef enum ptmi_status {
     PTMI_OK = 0,
@@ -124,6 +124,8 @@ typedef struct ptmi_scheduler_stats {
     uint64_t trips_triangle, lanes_triangle; /* leaf passes: triangles tested, one per lane */
     uint64_t trips_path, lanes_path;         /* path logic (shade / shadow set-up / scatter / regenerate) */
     uint64_t cycles_path, cycles_loop;       /* shader-clock cycles, summed over waves: inside path-logic passes / in the main loop */
+    uint64_t leaf_item_violations;           /* leaf passes: work items whose owner lane or triangle record index was out of range when a
+                                                lane read them (an item read before its writer: must be 0; checked only while collecting) */
 } ptmi_scheduler_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */

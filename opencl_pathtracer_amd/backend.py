@@ -70,12 +70,13 @@ class Counters(C.Structure):
 
 class SchedulerStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("trips_node", "lanes_node", "trips_triangle", "lanes_triangle", "trips_path",
-                                         "lanes_path", "cycles_path", "cycles_loop")]
+                                         "lanes_path", "cycles_path", "cycles_loop", "leaf_item_violations")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+USER_SNAPSHOT_SLOTS = 64  # ptmi.h: PTMI_MAX_SNAPSHOT_SLOTS - 1 (the last slot is the library's own)
 FLAG_NO_HISTOGRAMS = 1
 FLAG_SCHEDULER_STATS = 4  # collect scheduler_stats() (off by default)
 FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)

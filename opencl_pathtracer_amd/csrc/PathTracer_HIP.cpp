@@ -198,8 +198,10 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
                          last_image, numImagesToRender, g_devices, t_path, t_mem, t_disp);
     };
     // ---- bursts: B images per launch, a snapshot behind every one of them (ptmi_render_snapshots), one burst queued ahead
-    unsigned burst = env_uint("PTMI_BURST", 16);
+    // (with G devices a burst of B images is B / G iterations per device and launch: 16 per device, up to half the ring, so
+    // that the launches of a multi-GPU render stay as long as a single GPU's)
     const unsigned ring = PTMI_MAX_SNAPSHOT_SLOTS - 1;
+    unsigned burst = env_uint("PTMI_BURST", 16u * (g_devices > 1 ? g_devices : 1u));
     if (burst > ring / 2) burst = ring / 2;
     if (batch == 1 && burst > 1 && sampler_owns_pixels(globalVars)) {
         const uint bursts = (numImagesToRender + burst - 1) / burst;

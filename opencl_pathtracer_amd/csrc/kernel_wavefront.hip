@@ -73,6 +73,11 @@ constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 // mix 4K): 3: 415, 4: 500 / 2731 / 1382, 5: 533 / 2708 / 1375, 6: 409.
 #define PTMI_WF_MIN_WAVES 5
 #endif
+#ifndef PTMI_WF_MIN_WAVES_GENERAL
+// ... of the general shading specialisation (textures, all material and light types: twice the path-logic code of the
+// plain one), whose waves spend 40 % of their life in path logic on the material-mix scene
+#define PTMI_WF_MIN_WAVES_GENERAL 5
+#endif
 #ifndef PTMI_WF_QUEUES
 #define PTMI_WF_QUEUES 8
 #endif
@@ -86,7 +91,8 @@ constexpr int kWaitDebtFixed = PTMI_WF_WAIT_DEBT;
 // LDS words of the closest-hit record per lane.  8: hit point (4), s, t, triangle | front, found.  4: the ray parameter
 // instead of the point - path logic rebuilds the point from the ray it still holds with the very operations of the
 // triangle test, bit for bit - s, t, and one word triangle | front | found.  LDS per workgroup = (tree depth + 1 + words)
-// KB: with 4 words trees up to depth 27 keep five workgroups per CU (8 words: up to depth 22; the 4M-triangle scene is 24).
+// KB + 4 KB of leaf-pass keys and items (kLeafPassWords) = (depth + 9) KB with 4 words: trees up to depth 23 keep five
+// workgroups per CU (160 KB); the 4M-triangle scene (depth 24: 33 KB) and the 16M one (depth 27) run four.
 // Measured on MI355X, same box, 1M triangles 1080p: 4 words 759-761, 8 words 751-753 Msamples/s.
 #define PTMI_WF_HIT_WORDS 4
 #endif
@@ -166,7 +172,7 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
 // the registers - of the other material types, light types, samplers and of the light loop (1M triangles +4.9 %, Cornell
 // box +8.5 %).
 template <bool STATS, bool PRE, bool SS, bool PLAIN = false>
-__global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_kernel(
+__global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN_WAVES_GENERAL) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc_arg, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t iteration_stride,
                                                                     const uint32_t n_jobs,
@@ -345,7 +351,8 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
     unsigned long long* const key_mem = reinterpret_cast<unsigned long long*>(&stack_mem[(kHitWords + 1 + stack_levels) * kWfBlock]);
     uint2* const item_mem = reinterpret_cast<uint2*>(&stack_mem[(kHitWords + 3 + stack_levels) * kWfBlock]) + (tid & ~63u);
     const uint32_t lane = tid & 63u, wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid & ~63u));  // (a scalar)
-    uint32_t pass_rounds = 0, pass_items = 0;
+    uint32_t pass_rounds = 0, pass_items = 0, item_violations = 0;
+    const uint32_t n_records = STATS ? cold_scene().n_records : 0u;
     auto leaf_pass = [&](bool waits_at_leaf) {
         auto lanes_below = [&](unsigned long long m) {
             return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -378,6 +385,9 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
             auto fetch = [&](float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(x))); };
             const uint32_t w_tri = item.x & 0x7FFFFFFFu;
             const bool w_shadow = (item.x >> 31) != 0u;
+            // the item protocol's invariant, checked where statistics are collected (tests/test_parity_gpu.py): an item a lane
+            // reads was written by its owner in THIS pass - a stale one would name a lane or a record that may not exist
+            if (STATS && has_item && (owner >= 64u || w_tri >= n_records)) item_violations++;
             const float4* const rec = reinterpret_cast<const float4*>(&sc.tris[has_item ? w_tri : 0u]);
             constexpr int kE1 = PRE ? 1 : 3, kL0 = PRE ? 2 : 1, kL1 = PRE ? 3 : 2;
             const float4 e0 = rec[0], e1 = rec[kE1];  // (lanes without an item read record 0: in bounds, unused)
@@ -829,6 +839,7 @@ __global__ void __launch_bounds__(kWfBlock, PTMI_WF_MIN_WAVES) render_wavefront_
         atomicAdd(&block_counters[C_CYCLES_P], cycles_p);
         atomicAdd(&block_counters[C_CYCLES_LOOP], __builtin_amdgcn_s_memtime() - loop_start);
     }
+    if (STATS && item_violations != 0u) atomicAdd(&block_counters[C_ITEM_VIOLATIONS], (unsigned long long)item_violations);
     __syncthreads();
     // every surface hit sends one shadow ray to every light (Scene_ComputeDirectIllumination, :901-954)
     if (tid == 0) block_counters[C_SHADOW] = block_counters[C_HITS] * sc.n_lights;
@@ -967,16 +978,27 @@ static size_t wavefront_lds_bytes(uint32_t stack_levels)
     return ((size_t)(stack_levels + 1 + PTMI_DEV_NS::kHitWords) * PTMI_DEV_NS::kWfBlock + PTMI_DEV_NS::kLeafPassWords) * sizeof(uint32_t);
 }
 
-int PTMI_ARITH(wavefront_resident_blocks)(int device, uint32_t stack_levels)
+// workgroups of instantiation `kernel` the current device holds at once (the persistent grid): registers and LDS decide
+template <class Kernel>
+static int resident_blocks_of(Kernel kernel, uint32_t stack_levels)
 {
-    int per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PTMI_DEV_NS::render_wavefront_kernel<false, true, false>, PTMI_DEV_NS::kWfBlock,
-                                                     wavefront_lds_bytes(stack_levels)) != hipSuccess)
+    int device = 0, per_cu = 0, n_cu = 0;
+    if (hipGetDevice(&device) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PTMI_DEV_NS::kWfBlock, wavefront_lds_bytes(stack_levels)) != hipSuccess)
         return 0;
     if (per_cu < 1) per_cu = 1;
-    return per_cu * prop.multiProcessorCount;
+    return per_cu * n_cu;
+}
+
+int PTMI_ARITH(wavefront_resident_blocks)(int device, uint32_t stack_levels)
+{
+    int before = 0;
+    (void)hipGetDevice(&before);
+    if (hipSetDevice(device) != hipSuccess) return 0;
+    const int n = resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, true>, stack_levels);
+    (void)hipSetDevice(before);
+    return n;
 }
 
 int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
@@ -994,8 +1016,8 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
     hipError_t e = hipMemsetAsync(job_counter, 0, PTMI_DEV_NS::kQueues * PTMI_DEV_NS::kQueueStride * sizeof(uint32_t), (hipStream_t)stream);
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + PTMI_DEV_NS::kWfBlock - 1) / PTMI_DEV_NS::kWfBlock;
-        if (resident_blocks > 0 && blocks > (uint32_t)resident_blocks) blocks = (uint32_t)resident_blocks;
-        const dim3 g(blocks), b(PTMI_DEV_NS::kWfBlock);
+        (void)resident_blocks;
+        const dim3 b(PTMI_DEV_NS::kWfBlock);
         const size_t lds = wavefront_lds_bytes(stack_levels);
         const uint32_t lv = clamp_levels(stack_levels);
         hipStream_t st = (hipStream_t)stream;
@@ -1011,9 +1033,18 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         const bool plain = sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette &&
                            sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats;
         warm.wait_debt = lv >= 16u ? 768u : (plain ? 320u : 512u);  // (the cheaper a path-logic pass, the sooner it pays)
-#define PTMI_LAUNCH_WF_IMPL(S, P, A, L)                                                                              \
-    hipLaunchKernelGGL((PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L>), g, b, lds, st, scene_in_device_memory, warm, \
-                       first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats)
+        // the persistent grid of the chosen instantiation (they differ in registers, hence in workgroups per CU); the caller's
+        // `resident_blocks` (of the plain-scene instantiation) only caps it
+#define PTMI_LAUNCH_WF_IMPL(S, P, A, L)                                                                                   \
+    do {                                                                                                                  \
+        auto kernel = PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L>;                                                    \
+        static int resident[PTMI_BVH_MAX_DEPTH + 1] = {};                                                                  \
+        if (resident[lv] == 0) resident[lv] = resident_blocks_of(kernel, lv);                                             \
+        uint32_t nb = blocks;                                                                                             \
+        if (resident[lv] > 0 && nb > (uint32_t)resident[lv]) nb = (uint32_t)resident[lv];                                 \
+        hipLaunchKernelGGL(kernel, dim3(nb), b, lds, st, scene_in_device_memory, warm, first_iteration, n_iterations,      \
+                           iteration_stride, n_jobs, job_counter, lv, stage, stage_stats);                                \
+    } while (0)
 #define PTMI_LAUNCH_WF(S, P, A)                                                                                       \
     PTMI_LAUNCH_WF_IMPL(S, P, A, false)
         // instantiations: the common case (no statistics, no adaptive sampling) pays for neither

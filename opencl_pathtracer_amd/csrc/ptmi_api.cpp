@@ -6,6 +6,7 @@
 // of iterations; the scene is validated and re-laid out before upload).
 // No CPU fallback exists: without a HIP device nothing here computes.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <limits>
@@ -67,8 +68,16 @@ struct DeviceState {
     // ptmi_snapshot ring: float[5*W*H] per slot (colour, then count), allocated on first use
     float* d_snapshot[PTMI_MAX_SNAPSHOT_SLOTS] = {};
     hipEvent_t snapshot_ready[PTMI_MAX_SNAPSHOT_SLOTS] = {};
+    // Where this device's share of the image of ring slot s lives: slot s itself when its accumulators changed with that image,
+    // else the slot of the last image that changed them (a device of a G-device render changes with every G-th image only, so
+    // ptmi_render_snapshots copies 41.5 MB per OWN iteration instead of per image); -1 = the slot has never been filled.
+    int source_slot[PTMI_MAX_SNAPSHOT_SLOTS];
+    uint32_t snapshot_gen[PTMI_MAX_SNAPSHOT_SLOTS] = {};  // bumped by every copy into the slot
     float* d_peer_copy = nullptr;      // devices[0] only: where device k's snapshot lands before the sum, one per device
     hipEvent_t peer_copied = nullptr;  // ... and the event that says it has
+    int landed_slot = -1;              // ... and which snapshot it holds: (slot, generation) - a peer sends only what has changed
+    uint32_t landed_gen = 0;
+    DeviceState() { for (int& s : source_slot) s = -1; }
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -84,6 +93,11 @@ struct ptmi_ctx {
     std::string err;
     uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     uint32_t iterations_per_launch = kMaxIterationsPerLaunch;
+
+    // RCCL communicators, one per device of the context (single process, ncclCommInitAll): the sum of the devices' partial
+    // images is an ncclReduce over xGMI where librccl is present and the devices are distinct (rccl_reduce_snapshots)
+    std::vector<void*> rccl_comms;
+    int rccl_state = 0;  // 0 = not tried, 1 = ready, -1 = unavailable (peer copies + a sum kernel instead)
 
     // on devices[0]
     float* d_reduced = nullptr;    // sum of the devices' snapshots (n_devices > 1)
@@ -150,7 +164,9 @@ void free_scene_memory(ptmi_ctx* ctx)
             // ... and the event that says the slot is filled: a slot of the NEXT scene is empty until ptmi_snapshot fills it
             if (d.snapshot_ready[k]) (void)hipEventDestroy(d.snapshot_ready[k]);
             d.snapshot_ready[k] = nullptr;
+            d.source_slot[k] = -1;
         }
+        d.landed_slot = -1;
         if (d.d_peer_copy) (void)hipFree(d.d_peer_copy);
         d.d_peer_copy = nullptr;
     }
@@ -516,6 +532,8 @@ int snapshot_device(ptmi_ctx* ctx, DeviceState& d, uint32_t slot)
     HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot], d.ds.image_color, npix * 16, hipMemcpyDeviceToDevice, d.stream));
     HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot] + 4 * npix, d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToDevice, d.stream));
     HIP_TRY(ctx, hipEventRecord(d.snapshot_ready[slot], d.stream));
+    d.source_slot[slot] = (int)slot;
+    d.snapshot_gen[slot]++;
     return PTMI_OK;
 }
 int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
@@ -525,18 +543,31 @@ int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
     return PTMI_OK;
 }
 
-// ptmi_render_snapshots: a snapshot after EVERY iteration of the call although the iterations share launches.  Global
-// iteration first + k (k < n) goes to slot (first_slot + k) % PTMI_MAX_USER_SLOTS; a device snapshots for every k, with
-// whatever it has accumulated by then (its own ids up to first + k).
+// ptmi_render_snapshots: an image after EVERY iteration of the call although the iterations share launches.  Global
+// iteration first + k (k < n) goes to slot (first_slot + k) % PTMI_MAX_USER_SLOTS.  A device's share of image k is whatever
+// it has accumulated by then (its own ids up to first + k): it COPIES its accumulators only when they have changed since its
+// last copy of this call - once per own iteration, plus once at the start of the call (so that every image of a call is
+// served from slots of that call: a caller may be overwriting the previous call's) - and lets the other images of the call
+// point at that copy (source_slot).
 struct SnapshotPlan {
     uint32_t first, n, first_slot;
-    uint32_t next = 0;  // next global k to snapshot on this device
+    uint32_t next = 0;    // next global k to provide on this device
+    int last_slot = -1;   // this device's latest copy of this call
+    bool changed = true;  // accumulators changed since (or no copy of this call yet)
 };
 constexpr uint32_t kUserSlots = PTMI_MAX_SNAPSHOT_SLOTS - 1;  // the last slot is the library's own
 int snapshots_up_to(ptmi_ctx* ctx, DeviceState& d, SnapshotPlan& plan, uint32_t k_end)
 {
-    for (; plan.next < k_end && plan.next < plan.n; plan.next++)
-        if (int rc = snapshot_device(ctx, d, (plan.first_slot + plan.next) % kUserSlots)) return rc;
+    for (; plan.next < k_end && plan.next < plan.n; plan.next++) {
+        const uint32_t slot = (plan.first_slot + plan.next) % kUserSlots;
+        if (plan.changed || plan.last_slot < 0) {
+            if (int rc = snapshot_device(ctx, d, slot)) return rc;
+            plan.last_slot = (int)slot;
+            plan.changed = false;
+        } else {
+            d.source_slot[slot] = plan.last_slot;
+        }
+    }
     return PTMI_OK;
 }
 
@@ -637,6 +668,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                         if (rc != PTMI_OK) break;
                         rc = KERNELS_OF(ctx, launch_accumulate_staged)(d.ds, id, 1, stage + (size_t)j * npix * 4,
                                                                        stage_stats ? stage_stats + (size_t)j * npix : nullptr, false, d.stream, &err);
+                        plan->changed = true;
                         if (rc == PTMI_OK) rc = snapshots_up_to(ctx, d, *plan, id - plan->first + 1);
                     }
                     if (rc == PTMI_OK && stage_stats)
@@ -701,6 +733,94 @@ int copy_out(ptmi_ctx* ctx, hipStream_t stream, const float* d_color, const floa
     return PTMI_OK;
 }
 
+// ---- RCCL, loaded at run time (the library has no link-time dependency on it) --------------------------------------------
+// north_star: "samples-per-pixel shard across the GPUs of one node with an RCCL reduce of the framebuffer over xGMI".  One
+// process drives all devices of a context, so the communicators come from ncclCommInitAll and the G reduce calls of an image
+// are one group.  PTMI_REDUCE=peer forces the peer-copy path; PTMI_REDUCE=rccl-always sends even a one-device context through
+// a one-rank communicator (how the tests exercise this code on a one-GPU box).
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void* send, void* recv, size_t count, int datatype, int op, int root, void* comm, hipStream_t stream) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+        api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.Reduce = reinterpret_cast<decltype(api.Reduce)>(sym("ncclReduce"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.ok = api.CommInitAll && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Reduce;
+    });
+    return api;
+}
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+
+const char* reduce_mode()
+{
+    const char* e = std::getenv("PTMI_REDUCE");
+    return e ? e : "";
+}
+
+// devices[0]'s ctx->d_reduced = sum over the devices of their share of the image of ring slot `slot`, by ONE ncclReduce per
+// device (root = devices[0]), each on its device's copy stream behind that device's snapshot.  PTMI_ERR_UNSUPPORTED = this
+// context cannot use RCCL (library absent, a device listed twice, initialisation refused): the caller falls back to peer copies.
+int rccl_reduce_snapshots(ptmi_ctx* ctx, uint32_t slot)
+{
+    if (ctx->rccl_state < 0 || std::strcmp(reduce_mode(), "peer") == 0) return PTMI_ERR_UNSUPPORTED;
+    RcclApi& api = rccl_api();
+    const int G = (int)ctx->n_dev();
+    if (ctx->rccl_state == 0) {
+        ctx->rccl_state = -1;
+        if (!api.ok) return PTMI_ERR_UNSUPPORTED;
+        std::vector<int> devs;
+        for (DeviceState& d : ctx->dev) {
+            for (int o : devs)
+                if (o == d.device) return PTMI_ERR_UNSUPPORTED;  // RCCL wants distinct devices
+            devs.push_back(d.device);
+        }
+        ctx->rccl_comms.assign((size_t)G, nullptr);
+        if (api.CommInitAll(ctx->rccl_comms.data(), G, devs.data()) != 0) {
+            ctx->rccl_comms.clear();
+            (void)hipGetLastError();
+            return PTMI_ERR_UNSUPPORTED;
+        }
+        ctx->rccl_state = 1;
+    }
+    const size_t count = ctx->npix() * 5;
+    for (DeviceState& d : ctx->dev) {
+        ON_DEVICE(ctx, d);
+        HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, d.snapshot_ready[d.source_slot[slot]], 0));
+    }
+    int rc = api.GroupStart();
+    for (int k = 0; k < G && rc == 0; k++) {
+        DeviceState& d = ctx->dev[(size_t)k];
+        ON_DEVICE(ctx, d);
+        float* send = d.d_snapshot[d.source_slot[slot]];
+        rc = api.Reduce(send, k == 0 ? (void*)ctx->d_reduced : (void*)send, count, kNcclFloat32, kNcclSum, 0, ctx->rccl_comms[(size_t)k], d.copy_stream);
+    }
+    const int rc_end = api.GroupEnd();
+    if (rc == 0) rc = rc_end;
+    ON_DEVICE(ctx, ctx->dev[0]);
+    if (rc != 0) return fail(ctx, PTMI_ERR_HIP, std::string("ncclReduce: ") + (api.GetErrorString ? api.GetErrorString(rc) : "error"));
+    return PTMI_OK;
+}
+
 // The image of ring slot `slot` on devices[0], ordered on dev[0].copy_stream: the slot itself for one device; for several,
 // every other device's snapshot copied over (each on its own stream, so the transfers use their own xGMI links at the same
 // time) and the sum of all of them, in device order, in ctx->d_reduced.
@@ -709,15 +829,37 @@ int gather_snapshot(ptmi_ctx* ctx, uint32_t slot, const float** image)
     DeviceState& lead = ctx->dev[0];
     const size_t npix = ctx->npix();
     for (DeviceState& d : ctx->dev)
-        if (!d.snapshot_ready[slot]) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot of a slot no ptmi_snapshot has filled");
+        if (d.source_slot[slot] < 0 || !d.snapshot_ready[d.source_slot[slot]] || !d.d_snapshot[d.source_slot[slot]])
+            return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot of a slot no ptmi_snapshot has filled");
     ON_DEVICE(ctx, lead);
-    HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, lead.snapshot_ready[slot], 0));
-    if (ctx->n_dev() == 1) {
-        *image = lead.d_snapshot[slot];
+    const int lead_src = lead.source_slot[slot];
+    HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, lead.snapshot_ready[lead_src], 0));
+    if (ctx->n_dev() == 1 && std::strcmp(reduce_mode(), "rccl-always") != 0) {
+        *image = lead.d_snapshot[lead_src];
         return PTMI_OK;
     }
+    if (!ctx->d_reduced) {
+        void* p = nullptr;
+        HIP_TRY(ctx, hipMalloc(&p, npix * 20));
+        ctx->d_reduced = (float*)p;
+    }
+    // Which path: the final image of a render (ptmi_read_image / ptmi_read_display: every device's share is new) goes through the
+    // collective; the images of a progressive per-image loop (ptmi_render_snapshots: ONE device's share is new per image) through
+    // the incremental peer copies below, which move 1 / (G - 1) of what a reduce would.  PTMI_REDUCE=rccl: the collective always.
+    const bool collective = slot == PTMI_MAX_SNAPSHOT_SLOTS - 1 || std::strncmp(reduce_mode(), "rccl", 4) == 0;
+    if (int rc = collective ? rccl_reduce_snapshots(ctx, slot) : (int)PTMI_ERR_UNSUPPORTED) {
+        if (rc != PTMI_ERR_UNSUPPORTED) return rc;
+        if (ctx->n_dev() == 1) {  // (rccl-always on a box without the library)
+            *image = lead.d_snapshot[lead_src];
+            return PTMI_OK;
+        }
+    } else {
+        *image = ctx->d_reduced;
+        return PTMI_OK;
+    }
+    // peer copies + one sum kernel (also the path of a context that lists one device several times, which RCCL refuses)
     const float* parts[PTMI_MAX_DEVICES];
-    parts[0] = lead.d_snapshot[slot];
+    parts[0] = lead.d_snapshot[lead_src];
     // the previous sum must have read the landing buffers before they are overwritten: the peers' copies wait for the lead's
     // copy stream as it stands now
     hipEvent_t& gate = lead.peer_copied;
@@ -734,20 +876,22 @@ int gather_snapshot(ptmi_ctx* ctx, uint32_t slot, const float** image)
     }
     for (uint32_t k = 1; k < ctx->n_dev(); k++) {  // each peer pushes its snapshot over its own link, on a stream and with an event of its own device
         DeviceState& d = ctx->dev[k];
+        const int src = d.source_slot[slot];
+        // ... unless the landing buffer already holds that very snapshot: consecutive images of a G-device render differ in
+        // ONE device's share, so an image costs one 41.5 MB peer copy, not G - 1
+        if (d.landed_slot == src && d.landed_gen == d.snapshot_gen[src]) continue;
         ON_DEVICE(ctx, d);
         if (!d.peer_copied) HIP_TRY(ctx, hipEventCreateWithFlags(&d.peer_copied, hipEventDisableTiming));
         HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, gate, 0));
-        HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, d.snapshot_ready[slot], 0));
-        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_peer_copy, lead.device, d.d_snapshot[slot], d.device, npix * 20, d.copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(d.copy_stream, d.snapshot_ready[src], 0));
+        HIP_TRY(ctx, hipMemcpyPeerAsync(d.d_peer_copy, lead.device, d.d_snapshot[src], d.device, npix * 20, d.copy_stream));
         HIP_TRY(ctx, hipEventRecord(d.peer_copied, d.copy_stream));
+        d.landed_slot = src;
+        d.landed_gen = d.snapshot_gen[src];
     }
     ON_DEVICE(ctx, lead);
-    for (uint32_t k = 1; k < ctx->n_dev(); k++) HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, ctx->dev[k].peer_copied, 0));
-    if (!ctx->d_reduced) {
-        void* p = nullptr;
-        HIP_TRY(ctx, hipMalloc(&p, npix * 20));
-        ctx->d_reduced = (float*)p;
-    }
+    for (uint32_t k = 1; k < ctx->n_dev(); k++)
+        if (ctx->dev[k].peer_copied) HIP_TRY(ctx, hipStreamWaitEvent(lead.copy_stream, ctx->dev[k].peer_copied, 0));
     std::string err;
     if (int rc = launch_sum_images(ctx->d_reduced, parts, ctx->n_dev(), npix * 5, lead.copy_stream, &err)) return fail(ctx, rc, err);
     *image = ctx->d_reduced;
@@ -968,9 +1112,10 @@ int ptmi_read_snapshot(ptmi_ctx* ctx, uint32_t slot, float* image_color, float* 
     if (slot >= PTMI_MAX_SNAPSHOT_SLOTS) return fail(ctx, PTMI_ERR_INVALID_ARGUMENT, "snapshot slot out of range");
     if (!image_color && !image_ray_nb) {  // wait only: the snapshot has been taken on every device (clFinish of that image)
         for (DeviceState& d : ctx->dev) {
-            if (!d.snapshot_ready[slot]) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot of a slot no ptmi_snapshot has filled");
+            const int src = d.source_slot[slot];
+            if (src < 0 || !d.snapshot_ready[src]) return fail(ctx, PTMI_ERR_STATE, "ptmi_read_snapshot of a slot no ptmi_snapshot has filled");
             ON_DEVICE(ctx, d);
-            HIP_TRY(ctx, hipEventSynchronize(d.snapshot_ready[slot]));
+            HIP_TRY(ctx, hipEventSynchronize(d.snapshot_ready[src]));
         }
         return PTMI_OK;
     }
@@ -1134,6 +1279,7 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
     out->trips_triangle = h[C_TRIPS_T]; out->lanes_triangle = h[C_LANES_T];
     out->trips_path = h[C_TRIPS_P]; out->lanes_path = h[C_LANES_P];
     out->cycles_path = h[C_CYCLES_P]; out->cycles_loop = h[C_CYCLES_LOOP];
+    out->leaf_item_violations = h[C_ITEM_VIOLATIONS];
     return PTMI_OK;
 }
 
@@ -1248,6 +1394,9 @@ void ptmi_release(ptmi_ctx* ctx)
 {
     if (!ctx) return;
     free_scene_memory(ctx);
+    for (void* comm : ctx->rccl_comms)
+        if (comm) (void)rccl_api().CommDestroy(comm);
+    ctx->rccl_comms.clear();
     for (auto& r : ctx->pinned_host) (void)hipHostUnregister(r.p);
     (void)hipGetLastError();
     if (ctx->h_staging) (void)hipHostFree(ctx->h_staging);

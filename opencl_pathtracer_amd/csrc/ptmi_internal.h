@@ -96,6 +96,9 @@ enum CounterSlot {
     C_TRIPS_I, C_LANES_I, C_TRIPS_T, C_LANES_T, C_TRIPS_P, C_LANES_P,
     // ... and where its waves spend their life: shader clock cycles inside path-logic passes / in the whole main loop
     C_CYCLES_P, C_CYCLES_LOOP,
+    // leaf passes (STATS builds): items a lane read with an owner >= 64 or a record index >= n_records - the invariant of the
+    // item protocol (every item below the pass's count is written by its owner before any lane reads it) would be broken
+    C_ITEM_VIOLATIONS,
     C_COUNT
 };
 

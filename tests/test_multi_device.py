@@ -15,6 +15,7 @@ import cases
 import oracle_ffi as O
 from opencl_pathtracer_amd import Backend, PtmiError, render_scene, structs as S
 from opencl_pathtracer_amd.backend import device_share
+from opencl_pathtracer_amd import backend
 
 
 @pytest.mark.parametrize("first,n,G", [(0, 16, 1), (0, 16, 2), (5, 1, 4), (7, 13, 3), (0, 4096, 8), (3, 2, 8), (10, 0, 4),
@@ -164,13 +165,59 @@ def test_snapshot_ring_equals_blocking_loop(devices, scene_factory):
     with pytest.raises(PtmiError):
         be.read_snapshot(slots + 1)  # never filled
     with pytest.raises(PtmiError):
-        be.snapshot(32)  # the library's own slot
+        be.snapshot(backend.USER_SNAPSHOT_SLOTS)  # the library's own slot
     be.unpin_host_buffer(out[0])
     with pytest.raises(PtmiError):
         be.unpin_host_buffer(out[1])  # never pinned
     c, n = be.read_image(out=out)  # staging path again
     assert np.array_equal(c.view(np.uint32), expect[-1][0].view(np.uint32))
     be.release()
+
+
+@pytest.mark.gpu
+def test_eight_listed_devices_equal_the_single_context(scene_factory):
+    """BASELINE configs[3]'s device count (one GPU listed eight times here): ids spread over eight shares, eight partial images
+    summed on devices[0] - counts, histograms and counters equal the single-context render exactly, the image up to the order of
+    the float additions."""
+    w, h, d, n = 96, 64, 6, 24
+    sc = scene_factory("tris20k", w, h)
+    color, count, stats, counters = render_scene(sc, w, h, d, n)
+    c8, n8, s8, k8 = render_scene(sc, w, h, d, n, devices=[0] * 8)
+    assert np.array_equal(n8, count) and k8 == counters and all(np.array_equal(a, b) for a, b in zip(stats, s8))
+    assert np.allclose(c8, color, rtol=2e-6, atol=1e-6)
+    # ... and equals the sum of its eight parts rendered alone, in device order, bit for bit
+    acc = np.zeros_like(color)
+    for k in range(8):
+        be = Backend().setup_context(w, h, d, sc.lightsSize)
+        be.initialize_memory(sc)
+        for j in range(n // 8):
+            be.render(k + 8 * j, 1)
+        part, _ = be.read_image()
+        be.release()
+        acc = acc + part if k else part.copy()
+    assert np.array_equal(c8.view(np.uint32), acc.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_rccl_reduce_behind_the_c_abi(scene_factory, monkeypatch):
+    """The collective north_star names, reached through the reference API's readback: PTMI_REDUCE=rccl-always sends the image of
+    a (one-device) context through librccl's ncclReduce - loaded at run time, one-rank communicator from ncclCommInitAll, on the
+    context's copy stream - before it crosses the bus.  (With several DISTINCT devices that path is the default for
+    ptmi_read_image; a one-GPU box can only check the plumbing and that the sum of one share is that share.)"""
+    w, h, d, n = 64, 48, 4, 5
+    sc = scene_factory("cornell", w, h)
+    color, count, _, _ = render_scene(sc, w, h, d, n)
+    monkeypatch.setenv("PTMI_REDUCE", "rccl-always")
+    be = Backend().setup_context(w, h, d, sc.lightsSize)
+    be.initialize_memory(sc)
+    be.render(0, n)
+    be.snapshot(3)
+    c, cn = be.read_snapshot(3)
+    be.release()
+    assert np.array_equal(c.view(np.uint32), color.view(np.uint32)) and np.array_equal(cn, count)
+    # devices listed twice are refused by RCCL: the peer-copy sum takes over, silently
+    c2, n2, _, _ = render_scene(sc, w, h, d, n, devices=[0, 0])
+    assert np.array_equal(n2, count) and np.allclose(c2, color, rtol=2e-6, atol=1e-6)
 
 
 @pytest.mark.gpu
@@ -193,10 +240,11 @@ def test_multi_device_bit_exact_parts_vs_oracle(scene_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0], [0] * 8])
 def test_render_snapshots_leaves_every_image_of_the_per_image_loop(devices, scene_factory):
     """ptmi_render_snapshots(first, n): iterations share one launch, yet slot k holds exactly
-    what the reference's loop would have read back after image first + k."""
+    what the reference's loop would have read back after image first + k.  With G devices a device copies its accumulators only
+    when they changed (every G-th image) and devices[0] receives only the share that changed: same images."""
     w, h, d = 96, 64, 6
     sc = scene_factory("tris20k", w, h)
     first, n = 3, 20
@@ -215,9 +263,10 @@ def test_render_snapshots_leaves_every_image_of_the_per_image_loop(devices, scen
     be = Backend().setup_context(w, h, d, sc.lightsSize, devices=devices)
     be.initialize_memory(sc)
     be.render(0, first)
-    be.render_snapshots(first, n, first_slot=30)  # wraps around the 32 caller slots
+    ring = backend.USER_SNAPSHOT_SLOTS
+    be.render_snapshots(first, n, first_slot=ring - 2)  # wraps around the caller slots
     for k in range(n):
-        c, cn = be.read_snapshot((30 + k) % 32)
+        c, cn = be.read_snapshot((ring - 2 + k) % ring)
         assert np.array_equal(cn, expect[k][1]), k
         assert np.array_equal(c.view(np.uint32), expect[k][0].view(np.uint32)), k
     s2 = be.read_statistics()
@@ -225,7 +274,15 @@ def test_render_snapshots_leaves_every_image_of_the_per_image_loop(devices, scen
     final, _ = be.read_image()
     assert np.array_equal(final.view(np.uint32), expect[-1][0].view(np.uint32))
     with pytest.raises(PtmiError):
-        be.render_snapshots(0, 33)
+        be.render_snapshots(0, ring + 1)
+    # a new scene on the same context: the ring is empty again (a slot of the old scene must not be readable)
+    be.initialize_memory(sc)
+    with pytest.raises(PtmiError) as e:
+        be.read_snapshot(0)
+    assert e.value.code == -6
+    be.render_snapshots(0, 2)
+    c, cn = be.read_snapshot(1)
+    assert float(cn.min()) == 2.0 == float(cn.max())
     be.release()
     rnd = Backend().setup_context(w, h, d, sc.lightsSize, sampler=S.RANDOM)
     rnd.initialize_memory(sc)

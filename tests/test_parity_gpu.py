@@ -494,6 +494,29 @@ def test_vs_reference_kernel_on_gpu(case, scene_factory):
         assert np.array_equal(rms, floor), (rms, floor)
 
 
+@pytest.mark.parametrize("flags", [0, backend_flags.FLAG_DEFAULT_ARITHMETIC])
+def test_scheduler_statistics_and_the_leaf_pass_item_protocol(flags, scene_factory):
+    """PTMI_FLAG_SCHEDULER_STATS builds: same image as the production build, plausible trip counts - and ZERO leaf-pass items
+    read with an owner lane or a record index out of range (an item slot read before its final writer, the cause of the two
+    faults of round 2's experimental 'blind item writes' variant, would show here first)."""
+    name, sampler, w, h, d = cases.CASES["tris1m_160x90_d10"]
+    sc = scene_factory(name, w, h)
+    be = Backend().setup_context(w, h, d, sc.lightsSize, sampler, flags=flags | backend_flags.FLAG_SCHEDULER_STATS)
+    be.initialize_memory(sc)
+    be.render(0, 8)
+    color, count = be.read_image()
+    st, c = be.scheduler_stats(), be.counters()
+    be.release()
+    ref_color, ref_count, _, ref_c = render_scene(sc, w, h, d, 8, sampler=sampler, flags=flags)
+    assert np.array_equal(color.view(np.uint32), ref_color.view(np.uint32)) and np.array_equal(count, ref_count) and c == ref_c
+    assert st["leaf_item_violations"] == 0
+    assert st["trips_node"] > 0 and st["trips_triangle"] > 0 and st["trips_path"] > 0
+    # every counted triangle test was one item of one pass (a shadow query stops COUNTING at its first hit: items dealt out
+    # behind it in the same pass are tested and not counted)
+    assert c["triangle_tests"] <= st["lanes_triangle"] <= 1.2 * c["triangle_tests"]
+    assert 0 < st["cycles_path"] < st["cycles_loop"]
+
+
 # (case, samples per pixel): each BASELINE config's own sample count on its parity-size scene - config 2 (Cornell box)
 # 1024 spp, config 3 (1M triangles) 256 spp, config 5's stand-in (material mix) 2048 spp
 NORTH_STAR = [("cornell_64x48_d4", 1024), ("cornell_128x128_d8", 1024), ("tris20k_96x64_d6", 256),
