@@ -57,8 +57,9 @@ typedef struct ptmi_config {
     uint32_t ray_max_depth;  /* -D MAX_REFLECTION_NUMBER (globalVars.rayMaxDepth) */
     uint32_t lights_size;    /* -D LIGHTS_SIZE (globalVars.lightsSize) */
     uint32_t sampler;        /* PTMI_SAMPLER_* : -D SAMPLE_JITTERED / _RANDOM / _UNIFORM */
-    uint32_t super_sampling; /* -D SUPER_SAMPLING (globalVars.superSampling): adaptive sampling, FullKernel.cl:1152-1172,1219-1222;
-                                JITTERED / UNIFORM samplers only (PTMI_ERR_UNSUPPORTED otherwise) */
+    uint32_t super_sampling; /* -D SUPER_SAMPLING (globalVars.superSampling): adaptive sampling, FullKernel.cl:1152-1172,1219-1222.
+                                With the RANDOM sampler the reference races on the count / variance of the pixel a sample lands on;
+                                here those updates are atomic (results statistically equal, not bit-equal, to a serial evaluation) */
     uint32_t flags;          /* PTMI_FLAG_* */
     /* Multi-GPU render (the reference drives devices[0] only, OpenCL.cpp:363-366): n_devices > 1 replicates the scene on
      * devices[0..n_devices) and spreads the iteration ids of every ptmi_render call over them (device k takes the ids
@@ -127,6 +128,19 @@ typedef struct ptmi_scheduler_stats {
     uint64_t leaf_item_violations;           /* leaf passes: work items whose owner lane or triangle record index was out of range when a
                                                 lane read them (an item read before its writer: must be 0; checked only while collecting) */
 } ptmi_scheduler_stats;
+
+/* The reference's device-side consistency checks: with -D LOG_INFO (OpenCL.cpp:310, globalVars.printLogInfos) its kernel
+ * prints a line whenever one of the ASSERT / WARNING conditions of PathTracer_FullKernel_header.cl:21-48 fails.  Here the
+ * failures of the checks on the live path are COUNTED, in the same debug instantiation of the kernel that collects the
+ * scheduler statistics (PTMI_FLAG_SCHEDULER_STATS); all zero otherwise.  A clean render has zeros everywhere except
+ * statistics_out_of_range, which counts what the reference's histograms silently drop. */
+typedef struct ptmi_invariant_checks {
+    uint64_t sample_out_of_range;      /* FullKernel.cl:1217 "SAMPLER - invalid pixel" */
+    uint64_t normal_not_facing_ray;    /* :1275 "Kernel_Main incorrect normals": dot(dir, Ns) < 0 && dot(dir, Ng) < 0 */
+    uint64_t negative_direct_radiance; /* :951 "Scene_ComputeDirectIllumination incorrect radiance L" */
+    uint64_t scattered_below_surface;  /* header.cl:243 "Vector_PutInSameHemisphereAs": dot(out, N) > 0 */
+    uint64_t statistics_out_of_range;  /* :1325,1330 "global__rayIntersectionBBx / Tri to large": >= 5000 tests on one path */
+} ptmi_invariant_checks;
 
 /* ---- lifecycle ---------------------------------------------------------- */
 
@@ -210,6 +224,7 @@ void ptmi_release(ptmi_ctx* ctx);
 
 int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out);
 int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out);
+int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out);
 
 /* Device time of the integrator kernel launches issued by ptmi_render since the
  * last call, measured with HIP events on the context's stream.  Synchronises. */

@@ -77,6 +77,14 @@ class SchedulerStats(C.Structure):
 
 
 USER_SNAPSHOT_SLOTS = 64  # ptmi.h: PTMI_MAX_SNAPSHOT_SLOTS - 1 (the last slot is the library's own)
+class InvariantChecks(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("sample_out_of_range", "normal_not_facing_ray", "negative_direct_radiance",
+                                         "scattered_below_surface", "statistics_out_of_range")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 FLAG_NO_HISTOGRAMS = 1
 FLAG_SCHEDULER_STATS = 4  # collect scheduler_stats() (off by default)
 FLAG_MEGAKERNEL = 2  # one path per lane instead of the persistent wavefront kernel (same results)
@@ -87,7 +95,7 @@ FLAG_DEFAULT_ARITHMETIC = 16
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats",
+               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats", "ptmi_get_invariant_checks",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
@@ -126,6 +134,7 @@ def load_library():
     lib.ptmi_release.restype = None
     lib.ptmi_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.ptmi_get_scheduler_stats.argtypes = [vp, C.POINTER(SchedulerStats)]
+    lib.ptmi_get_invariant_checks.argtypes = [vp, C.POINTER(InvariantChecks)]
     lib.ptmi_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
     lib.ptmi_set_stream.argtypes = [vp, vp]
     lib.ptmi_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -305,6 +314,12 @@ class Backend:
     def scheduler_stats(self):
         s = SchedulerStats()
         self._check(self._lib.ptmi_get_scheduler_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def invariant_checks(self):
+        """Failures of the reference's -D LOG_INFO device-side checks, counted by FLAG_SCHEDULER_STATS builds (ptmi.h)."""
+        s = InvariantChecks()
+        self._check(self._lib.ptmi_get_invariant_checks(self._ctx, C.byref(s)))
         return s.as_dict()
 
     def kernel_time(self):

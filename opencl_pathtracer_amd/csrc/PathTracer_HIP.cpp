@@ -137,6 +137,9 @@ void OpenCL_SetupContext(GlobalVars& globalVars, Sampler sampler)
     // arithmetic), so that a caller of the reference API gets the reference's images bit for bit; PTMI_STRICT_ARITHMETIC=1
     // selects the other bit-exact mode (the build the same source gives with correctly rounded operations).
     cfg.flags = env_uint("PTMI_STRICT_ARITHMETIC", 0) ? 0u : PTMI_FLAG_DEFAULT_ARITHMETIC;
+    // globalVars.printLogInfos is the reference's -D LOG_INFO (OpenCL.cpp:310): its kernel then checks its invariants on the device
+    // (header.cl:21-48).  Here: the kernel instantiation that counts the failures of those checks (report_invariant_checks).
+    if (globalVars.printLogInfos) cfg.flags |= PTMI_FLAG_SCHEDULER_STATS;
     const int rc = ptmi_setup_context(&g_ctx, &cfg);
     if (rc) fail("OpenCL_SetupContext", rc);
 }
@@ -166,6 +169,18 @@ void OpenCL_InitializeMemory(GlobalVars& globalVars)
     sc.camera_up = *reinterpret_cast<const ptmi_float4*>(&globalVars.cameraUp);
     const int rc = ptmi_initialize_memory(g_ctx, &sc);
     if (rc) fail("OpenCL_InitializeMemory", rc);
+}
+
+// What the reference prints line by line from its kernel with -D LOG_INFO, as totals after the render (only in that mode)
+static void report_invariant_checks(const GlobalVars& globalVars)
+{
+    if (!globalVars.printLogInfos || !g_ctx) return;
+    ptmi_invariant_checks c{};
+    if (ptmi_get_invariant_checks(g_ctx, &c) != PTMI_OK) return;
+    std::fprintf(stderr, "[ptmi] device-side checks (FullKernel_header.cl:21-48): SAMPLER - invalid pixel %llu, Kernel_Main incorrect normals %llu, "
+                         "incorrect radiance L %llu, Vector_PutInSameHemisphereAs %llu, rayIntersection histogram overflow %llu\n",
+                 (unsigned long long)c.sample_out_of_range, (unsigned long long)c.normal_not_facing_ray, (unsigned long long)c.negative_direct_radiance,
+                 (unsigned long long)c.scattered_below_surface, (unsigned long long)c.statistics_out_of_range);
 }
 
 void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), uint numImagesToRender,
@@ -228,6 +243,7 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
         }
         const int rc = ptmi_read_statistics(g_ctx, globalVars.rayDepths, globalVars.rayIntersectedBBx, globalVars.rayIntersectedTri);
         if (rc) fail("OpenCL_RunKernel (statistics)", rc);
+        report_invariant_checks(globalVars);
         ptmi_release(g_ctx);
         g_ctx = nullptr;
         return;
@@ -254,6 +270,7 @@ void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), ui
     }
     const int rc = ptmi_read_statistics(g_ctx, globalVars.rayDepths, globalVars.rayIntersectedBBx, globalVars.rayIntersectedTri);
     if (rc) fail("OpenCL_RunKernel (statistics)", rc);
+    report_invariant_checks(globalVars);
     ptmi_release(g_ctx);
     g_ctx = nullptr;
 }

@@ -267,6 +267,10 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
     unsigned long long cycles_p = 0;
     const unsigned long long loop_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
 
+    // the reference's -D LOG_INFO checks (header.cl:21-48), counted in the statistics build instead of printed (ptmi_invariant_checks)
+    auto check = [&](bool holds, int slot) {
+        if (STATS && !holds) atomicAdd(&block_counters[slot], 1ull);
+    };
     // statistics + accumulation of a finished path (FullKernel.cl:1319-1345).  `missed`: the path ended on a sky miss,
     // i.e. it made one closest-hit query more than it has surface hits.
     auto finish_path = [&](bool missed) {
@@ -283,6 +287,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
         atomicAdd(&totals[C_SEGMENTS], (unsigned long long)(reflection + (missed ? 1u : 0u)));
         atomicAdd(&totals[C_BBX], (unsigned long long)p_bbx);
         atomicAdd(&totals[C_TRI], (unsigned long long)p_tri);
+        check(p_bbx < PTMI_MAX_INTERSECTION_NUMBER && p_tri < PTMI_MAX_INTERSECTION_NUMBER, C_CHK_STATS_RANGE);  // cl:1325,1330
         if (sc.histograms && stage_stats == nullptr) {
             // RANDOM sampler / very deep paths: the three statistics atomics as the reference issues them (:1319-1331)
             const DScene& cs = cold_scene();
@@ -310,11 +315,26 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
             draw_sample(sc, gx, gy, it, seed0, sample_x, sample_y);
             const uint32_t off = sample_pixel(sc, sample_x, sample_y);
             const DScene& cs = cold_scene();
-            atomicAdd(&cs.image_color[4 * off + 0], radiance.x);
-            atomicAdd(&cs.image_color[4 * off + 1], radiance.y);
-            atomicAdd(&cs.image_color[4 * off + 2], radiance.z);
-            atomicAdd(&cs.image_color[4 * off + 3], radiance.w);
-            atomicAdd(&cs.image_ray_nb[off], 1.f);
+            // (the atomics return what the accumulators held before: sumBefore / nRayBefore of :1339-1342)
+            const V4 before = v4(atomicAdd(&cs.image_color[4 * off + 0], radiance.x), atomicAdd(&cs.image_color[4 * off + 1], radiance.y),
+                                 atomicAdd(&cs.image_color[4 * off + 2], radiance.z), atomicAdd(&cs.image_color[4 * off + 3], radiance.w));
+            const float n_before = atomicAdd(&cs.image_ray_nb[off], 1.f);
+            if (SS) {
+                // SUPER_SAMPLING with the RANDOM sampler (:1346-1349): the reference read-modify-writes the variance of a pixel
+                // other work-items may be updating too; here every update is an atomic add.  As in the reference, a pixel whose
+                // first sample arrives after iteration 0 divides 0 by 0 here, keeps a NaN variance and is never skipped (:1168:
+                // the comparison with NaN is false) - with this sampler 29 % of the pixels get no sample in iteration 0, so that
+                // quirk decides how many samples a render takes and is kept (the staged form guards its one such case instead).
+                float* const vp = &cs.image_v[4 * off];
+                if (it != 0u) {
+                    const V4 after = before + radiance;
+                    const float n_after = n_before + 1.f;
+                    atomicAdd(&vp[0], (radiance.x - fdiv(before.x, n_before)) * (radiance.x - fdiv(after.x, n_after)));
+                    atomicAdd(&vp[1], (radiance.y - fdiv(before.y, n_before)) * (radiance.y - fdiv(after.y, n_after)));
+                    atomicAdd(&vp[2], (radiance.z - fdiv(before.z, n_before)) * (radiance.z - fdiv(after.z, n_after)));
+                    atomicAdd(&vp[3], (radiance.w - fdiv(before.w, n_before)) * (radiance.w - fdiv(after.w, n_after)));
+                }
+            }
         }
         need_path = true;
         cur = REF_NONE; tri_i = tri_end = 0;
@@ -693,6 +713,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                     Ray arrival;
                     arrival.o = hit.point; arrival.d = cam_d; arrival.ix = arrival.iy = arrival.iz = 0;
                     load_surface<PLAIN>(sc, arrival, hit, sf);
+                    check(dot(cam_d, sf.Ns) < 0 && dot(cam_d, sf.Ng) < 0, C_CHK_NORMALS);  // cl:1275
                     V4 gathered = kOneLight ? v4(0, 0, 0, 0) : direct;
                     if (lit) {
                         ptmi_light light = sc.lights[kOneLight ? 0u : light_idx];
@@ -700,11 +721,14 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                         const float brdf = material_brdf(sf.mat.type, -r.d, sf.Ns, cam_d);
                         gathered = mad(v4(1, 1, 1, 1) * (light_power_toward(light, hit.point, sf.Ns) * brdf), v4(light.color), gathered);  // cl:945
                         if (!kOneLight) direct = gathered;
+                        check(gathered.x >= 0 && gathered.y >= 0 && gathered.z >= 0, C_CHK_RADIANCE);  // cl:951
                     }
                     if (do_scatter) {
                         r.d = cam_d;
                         V4 out;
-                        radiance = radiance + scatter_direction(r, seed, in_water, sf, gathered, transfer, out);
+                        V4 out_normal = v4(0, 0, 0, 0);
+                        radiance = radiance + scatter_direction(r, seed, in_water, sf, gathered, transfer, out, STATS ? &out_normal : nullptr);
+                        check(dot(out, out_normal) > 0.0f, C_CHK_HEMISPHERE);  // header.cl:243
                         r.o = mad(out, 0.001f, hit.point);  // :880 uses the un-normalised direction
                         reflection++;
                         shadow = false;
@@ -782,6 +806,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                 seed = lcg_seed(gx, gy, sc.width, sc.height, it);
                 float sample_x, sample_y;
                 draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
+                check(sample_x >= -0.5f && sample_y >= -0.5f && sample_x <= 0.5f && sample_y <= 0.5f, C_CHK_SAMPLE);  // cl:1217
                 {
                     const DScene& cs = cold_scene();  // camera: only needed here, once per path
                     r.o = v4(cs.cam_pos);
@@ -798,7 +823,8 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                     // superSamplingStopCriteria, FullKernel.cl:1152-1172 (called at :1219-1222, one launch per
                     // iteration so the accumulators hold iterations < it); draws one random number
                     const DScene& cs = cold_scene();
-                    const uint32_t off = gy * sc.width + gx;
+                    // the pixel the SAMPLE falls on (:1159-1161): the work-item's own with JITTERED / UNIFORM, any with RANDOM
+                    const uint32_t off = owns_pixel ? gy * sc.width + gx : sample_pixel(sc, sample_x, sample_y);
                     const float n = cs.image_ray_nb[off];
                     const float4 vv = reinterpret_cast<const float4*>(cs.image_v)[off];
                     const float sigma2_n = fmaxf(fmaxf(fdiv(vv.x, n), fdiv(vv.y, n)), fdiv(vv.z, n));
@@ -807,7 +833,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                     skip = (double)lcg_random(seed) > (double)fdiv(100 * sigma2_n, cs.x2inv[idx]) + 0.05;
                 }
                 if (skip) {
-                    cold_scene().stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
+                    if (owns_pixel) cold_scene().stage_flag[gy * sc.width + gx] = 0.f;  // returns before statistics and accumulation
                     need_path = true;
                 } else
                 if (sc.max_depth > 0) {

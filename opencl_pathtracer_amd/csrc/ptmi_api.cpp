@@ -944,9 +944,8 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
     if (cfg->lights_size >= PTMI_MAX_LIGHT_SIZE)  // PathTracer.cpp:60-65
         return fail(nullptr, PTMI_ERR_LIMIT, "lights_size >= 30");
     if (cfg->n_devices > PTMI_MAX_DEVICES) return fail(nullptr, PTMI_ERR_INVALID_ARGUMENT, "n_devices > PTMI_MAX_DEVICES");
-    if (cfg->super_sampling && (cfg->sampler == PTMI_SAMPLER_RANDOM || (cfg->flags & PTMI_FLAG_MEGAKERNEL)))
-        return fail(nullptr, PTMI_ERR_UNSUPPORTED,
-                    "SUPER_SAMPLING needs a sampler that owns its pixel (JITTERED/UNIFORM) and the wavefront kernel");
+    if (cfg->super_sampling && (cfg->flags & PTMI_FLAG_MEGAKERNEL))
+        return fail(nullptr, PTMI_ERR_UNSUPPORTED, "SUPER_SAMPLING needs the wavefront kernel");
 
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -1280,6 +1279,18 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
     out->trips_path = h[C_TRIPS_P]; out->lanes_path = h[C_LANES_P];
     out->cycles_path = h[C_CYCLES_P]; out->cycles_loop = h[C_CYCLES_LOOP];
     out->leaf_item_violations = h[C_ITEM_VIOLATIONS];
+    return PTMI_OK;
+}
+
+int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out)
+{
+    if (!ctx || !out) return PTMI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return fail(ctx, PTMI_ERR_STATE, "ptmi_get_invariant_checks before ptmi_initialize_memory");
+    unsigned long long h[C_COUNT];
+    if (int rc = read_counter_block(ctx, h)) return rc;
+    out->sample_out_of_range = h[C_CHK_SAMPLE]; out->normal_not_facing_ray = h[C_CHK_NORMALS];
+    out->negative_direct_radiance = h[C_CHK_RADIANCE]; out->scattered_below_surface = h[C_CHK_HEMISPHERE];
+    out->statistics_out_of_range = h[C_CHK_STATS_RANGE];
     return PTMI_OK;
 }
 

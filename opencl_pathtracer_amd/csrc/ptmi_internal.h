@@ -99,6 +99,12 @@ enum CounterSlot {
     // leaf passes (STATS builds): items a lane read with an owner >= 64 or a record index >= n_records - the invariant of the
     // item protocol (every item below the pass's count is written by its owner before any lane reads it) would be broken
     C_ITEM_VIOLATIONS,
+    // the reference's device-side checks (-D LOG_INFO: ASSERT / WARNING of header.cl:21-48), counted instead of printed, in STATS builds:
+    C_CHK_SAMPLE,      // cl:1217  the sample position lies in [-0.5, 0.5]^2
+    C_CHK_NORMALS,     // cl:1275  geometric and shading normal both face the arriving ray
+    C_CHK_RADIANCE,    // cl:951   the light gathered at a hit is non-negative
+    C_CHK_HEMISPHERE,  // h:243    the scattered direction lies in the hemisphere of its normal after Vector_PutInSameHemisphereAs
+    C_CHK_STATS_RANGE, // cl:1325,1330  a path's box / triangle test count fits the 5000-bin histograms
     C_COUNT
 };
 

@@ -49,7 +49,7 @@ __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, con
 // (split in two so that a caller with several sources of new rays can share ONE copy of the ray set-up, which holds
 // four divisions: scatter_direction = everything up to the outgoing direction `out`, un-normalised as :880 uses it)
 __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& in_water, const Surface& sf, V4 direct,
-                                                V4& transfer, V4& out_direction)
+                                                V4& transfer, V4& out_direction, V4* hemisphere_normal = nullptr)
 {
     V4 N = r.d;
     V4 radiance = v4(0, 0, 0, 0);
@@ -96,6 +96,7 @@ __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& i
     }
     if (diffuse) out = cosine_sample_hemisphere(seed, sf.Ns);
     out_direction = put_in_same_hemisphere(out, N);
+    if (hemisphere_normal) *hemisphere_normal = N;  // (for the statistics build's check of header.cl:243)
     return radiance;
 }
 

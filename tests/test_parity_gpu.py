@@ -321,12 +321,9 @@ def test_display_scanlines_equal_the_host_quantisation(scene_factory):
 def test_reinitialising_and_releasing_returns_the_device_memory(scene_factory):
     """Every allocation of ptmi_initialize_memory / ptmi_render / ptmi_read_display is released again (a 33 KB block
     once was not): free device memory after 40 set-up / render / release cycles equals the level after the first."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
+    import torch  # (device-memory query only: a second, ctypes-loaded HIP runtime may not see the device on every box)
     def free_bytes():
-        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
-        return f.value
+        return torch.cuda.mem_get_info(0)[0]
     sc = scene_factory("tris20k", 64, 48)
     levels = []
     for k in range(40):
@@ -337,7 +334,8 @@ def test_reinitialising_and_releasing_returns_the_device_memory(scene_factory):
         be.read_display()
         be.release()
         levels.append(free_bytes())
-    assert levels[-1] >= levels[0] - (1 << 20), (levels[0], levels[-1])  # (allocator granularity: well under 40 x 33 KB)
+    # (from the fifth cycle on: in a fresh process the HIP runtime itself still grows its pools - 8 MiB once - during the first)
+    assert levels[-1] >= levels[5] - (1 << 20), (levels[5], levels[-1])  # (allocator granularity: well under 35 x 33 KB)
     assert max(levels[5:]) - min(levels[5:]) <= (2 << 20)
 
 
@@ -506,10 +504,14 @@ def test_scheduler_statistics_and_the_leaf_pass_item_protocol(flags, scene_facto
     be.render(0, 8)
     color, count = be.read_image()
     st, c = be.scheduler_stats(), be.counters()
+    be_checks = be.invariant_checks()
     be.release()
     ref_color, ref_count, _, ref_c = render_scene(sc, w, h, d, 8, sampler=sampler, flags=flags)
     assert np.array_equal(color.view(np.uint32), ref_color.view(np.uint32)) and np.array_equal(count, ref_count) and c == ref_c
     assert st["leaf_item_violations"] == 0
+    # the reference's -D LOG_INFO device-side checks (header.cl:21-48), counted by this build: a clean render
+    assert be_checks == {"sample_out_of_range": 0, "normal_not_facing_ray": 0, "negative_direct_radiance": 0,
+                         "scattered_below_surface": 0, "statistics_out_of_range": 0}
     assert st["trips_node"] > 0 and st["trips_triangle"] > 0 and st["trips_path"] > 0
     # every counted triangle test was one item of one pass (a shadow query stops COUNTING at its first hit: items dealt out
     # behind it in the same pass are tested and not counted)

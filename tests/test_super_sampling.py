@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_ffi as O
-from opencl_pathtracer_amd import PtmiError, render_scene, structs as S
+from opencl_pathtracer_amd import Backend, PtmiError, render_scene, structs as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_TABLE = "/root/reference/Kernel/X2inv.cl"
@@ -56,8 +56,39 @@ def test_unsupported_combinations_fail_loudly(built):
     if lib.ptmi_device_count() == 0:
         pytest.skip("argument check happens after device discovery only for valid configs; needs no GPU otherwise")
     with pytest.raises(PtmiError) as e:
-        backend.Backend().setup_context(8, 8, 2, 0, sampler=S.RANDOM, super_sampling=True)
+        backend.Backend().setup_context(8, 8, 2, 0, super_sampling=True, flags=backend.FLAG_MEGAKERNEL)
     assert e.value.code == -7
+
+
+@pytest.mark.gpu
+def test_super_sampling_with_the_random_sampler(scene_factory):
+    """SUPER_SAMPLING x SAMPLE_RANDOM, a combination the reference compiles and runs (FullKernel.cl:1137-1141 with :1152-1172,
+    :1219-1222): samples land on arbitrary pixels, so the stop test reads - and the epilogue updates - the count and variance
+    of a pixel other work-items are updating too.  The reference races there; here every update is an atomic.  Against the
+    serial oracle the comparison is therefore statistical: the same estimator and nearly the same stop decisions."""
+    w, h, d, n = 64, 48, 4, 24
+    sc = scene_factory("cornell", w, h)
+    be = Backend().setup_context(w, h, d, sc.lightsSize, sampler=S.RANDOM, super_sampling=True)
+    be.initialize_memory(sc)
+    be.render(0, n)
+    color, count = be.read_image()
+    var = be.read_variance()
+    (dep, _, _), counters = be.read_statistics(), be.counters()
+    be.release()
+    o_color, o_count, (o_dep, _, _), totals = O.oracle_render(sc, w, h, d, n, sampler=S.RANDOM, super_sampling=True)
+    assert np.isfinite(color).all()
+    assert int(count.sum()) == counters["paths"] == int(dep.sum()) < w * h * n  # some paths were skipped ...
+    assert abs(int(count.sum()) - int(o_count.sum())) <= 0.02 * o_count.sum()  # ... about as many as the serial evaluation skips
+    assert np.abs(dep.astype(np.int64) - o_dep.astype(np.int64)).sum() <= 0.03 * o_dep.sum()
+    a = color[..., :3].sum(axis=(0, 1)) / count.sum()
+    b = o_color[..., :3].sum(axis=(0, 1)) / o_count.sum()
+    assert np.allclose(a, b, rtol=0.02)
+    # a pixel whose first sample came after iteration 0 has a NaN variance in the reference (0 / 0, :1349) and is never skipped
+    o_var = np.zeros((h, w, 4), np.float32)
+    O.oracle_render(sc, w, h, d, n, sampler=S.RANDOM, super_sampling=True, image_v=o_var)
+    assert abs(int(np.isnan(var[..., 0]).sum()) - int(np.isnan(o_var[..., 0]).sum())) <= 0.05 * np.isnan(o_var[..., 0]).sum() + 5
+    ok = ~np.isnan(var[..., :3])
+    assert (var[..., :3][ok] >= -1e-3).all() and var[..., :3][ok].max() > 0  # sums of products of same-signed deviations
 
 
 @pytest.mark.gpu
