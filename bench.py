@@ -507,7 +507,17 @@ def cpu_baseline(scene, W, H, D, rows, n_iter, default_arithmetic=False):
     t0 = time.perf_counter()
     _, _, _, totals = oracle_rows(O, scene, W, H, D, rows, cores, n_iter, default_arithmetic)
     dt = time.perf_counter() - t0
+    # the port next to the reference's own CPU path (its kernel compiled for x86-64, measured once by the survey in the build
+    # container; tools/cpu_port_vs_reference.py times the port on the same workload shape there): per-thread speed ratio
+    ratio = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_reference_vs_port.json")))
+        ratio = {"port_over_reference_per_thread": rec["port_over_reference_one_thread"]["default" if default_arithmetic else "strict"],
+                 "source": "profiles/r03_cpu_reference_vs_port.json (build container, 1 thread, 1M triangles 256x144 2 spp depth 10)"}
+    except (OSError, KeyError, ValueError):
+        pass
     return {"value": totals["segments"] / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "port_vs_reference_cpu_path": ratio,
             "arithmetic": "default" if default_arithmetic else "strict",
             "sample": f"iterations 0..{n_iter - 1} of rows 0..{rows - 1} of the {W}x{H} image ({n_iter * rows * W} paths, "
                       f"{totals['segments']} segments) in {dt:.1f} s on {cores} threads",
