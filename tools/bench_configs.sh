@@ -4,11 +4,11 @@
 #   configs[1] Cornell box 1920x1080, 1024 spp, 8 bounces
 #   configs[2] 1M random triangles 1920x1080, 256 spp (the headline workload; bench.py's default at 16 spp per step)
 #   configs[4] stand-in: textured multi-material scene, 3840x2160, 16 bounces (the Maya asset does not exist), 64 of its 2048 spp
-#   tris4m     HBM regime: 4M triangles = 427 MB of records, beyond the Infinity Cache
+#   tris4m     4M triangles = 427 MB of records, beyond the Infinity Cache (still not HBM-bound)
 # usage: tools/bench_configs.sh [names...]
 mkdir -p gpurun_out
-run() { name=$1; shift; echo "== $name: bench.py $*"; python bench.py "$@" > gpurun_out/r02_bench_$name.json 2> gpurun_out/r02_bench_$name.err || tail -3 gpurun_out/r02_bench_$name.err;
-        python -c "import json,sys; d=json.load(open('gpurun_out/r02_bench_$name.json')); print('$name', round(d['value'],1), d['unit'], '| roofline frac', round(d['roofline']['frac'],3), '| cpu', d.get('cpu_baseline',{}).get('value'), '| boundary', d.get('boundary',{}).get('per_image_vs_batched'))"; }
+run() { name=$1; shift; echo "== $name: bench.py $*"; python bench.py "$@" > gpurun_out/r03_bench_$name.json 2> gpurun_out/r03_bench_$name.err || tail -3 gpurun_out/r03_bench_$name.err;
+        python -c "import json,sys; d=json.load(open('gpurun_out/r03_bench_$name.json')); print('$name', round(d['value'],1), d['unit'], '| roofline frac', round(d['roofline']['frac'],3), '| cpu', d.get('cpu_baseline',{}).get('value'), '| boundary', d.get('boundary',{}).get('per_image_vs_batched'))"; }
 want="$@"; [ -z "$want" ] && want="config0 config1 config2 config4 tris4m"
 for n in $want; do case $n in
   config0) run config0_cornell_512_d4_64spp --scene cornell --width 512 --height 512 --depth 4 --steps 4 --warmup 0 --cpu-spp 64 --cpu-rows 512;;
