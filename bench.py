@@ -494,14 +494,14 @@ def cpu_baseline(scene, W, H, D, rows, n_iter, default_arithmetic=False):
     import oracle_ffi as O
     cores = host_cores()
     if rows <= 0 or n_iter <= 0:
-        # a short probe gives this scene's rate; then aim at ~15 s of CPU work, whole images first
+        # a short probe gives this scene's rate; then aim at ~20 s of CPU work (10-30 s), whole images first
         probe_rows = max(cores, min(H, 4 * cores))
         t0 = time.perf_counter()
         _, _, _, tot = oracle_rows(O, scene, W, H, D, probe_rows, cores, 1, default_arithmetic)
         rate = tot["paths"] / max(time.perf_counter() - t0, 1e-6)
-        target_paths = 15.0 * rate
+        target_paths = 20.0 * rate
         if n_iter <= 0:
-            n_iter = max(1, min(64, int(target_paths // (W * H))))
+            n_iter = max(1, min(64, int(target_paths / (W * H) + 0.5)))
         if rows <= 0:
             rows = H if target_paths >= W * H else max(cores, int(target_paths // W))
     t0 = time.perf_counter()

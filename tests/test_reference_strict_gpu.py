@@ -118,7 +118,9 @@ def test_zero_seed_paths_follow_the_compiled_reference(scene_factory):
     (oracle/pt_oracle.c).  96 x 96: index = x + 96 y + 9216 it is a multiple of 65536 for (64, 42) at iteration 28."""
     case = "matmix_96x96_d8"
     if not O.have_ref_kernel(case, strict=True):
-        pytest.skip("oracle/_ref strict code object not present")
+        # the behaviour is tied to what one compiler makes of an undefined overflow (verified: the image's clang 22 / ROCm 7.2, both
+        # builds of the reference kernel): where it cannot be re-verified the test must say so loudly, not pass by skipping
+        pytest.fail("oracle/_ref strict code object not present: the seed-0 behaviour of the compiled reference cannot be verified")
     name, sampler, w, h, d = cases.CASES[case]
     assert (64 + 96 * 42 + 9216 * 28) % 65536 == 0
     sc = scene_factory(name, w, h)
@@ -126,5 +128,9 @@ def test_zero_seed_paths_follow_the_compiled_reference(scene_factory):
     g, _, _, _ = render_scene(sc, w, h, d, 1, first_iteration=28)
     o, _, _, _ = O.oracle_render(sc, w, h, d, 1, first_iteration=28)
     assert np.array_equal(g.view(np.uint32), r.view(np.uint32)) and np.array_equal(o.view(np.uint32), g.view(np.uint32))
+    # ... and the same in the arithmetic of the reference's own build
+    r2, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1, first_iteration=28)
+    g2, _, _, _ = render_scene(sc, w, h, d, 1, first_iteration=28, flags=16)
+    assert np.array_equal(g2.view(np.uint32), r2.view(np.uint32))
     bounces, _ = O.oracle_trace(sc, w, h, d, 64, 42, 28)
     assert bounces and all(b.seed_after == 0 for b in bounces)
