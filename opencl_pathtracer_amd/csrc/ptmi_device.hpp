@@ -194,8 +194,10 @@ __device__ __forceinline__ float lcg_random(int& seed)
 }
 
 // InitializeRandomSeed, header.cl:255-264 (all arithmetic is modulo 2^32).  The reference's `if(seed == 0) seed = 1` follows a
-// signed square whose overflow is undefined; the OpenCL compilers it meets (LLVM: verified in the gfx950 code object) test
-// the un-squared index instead, so a square that wraps to 0 leaves the seed 0 - and every random number of that path 0.
+// signed square whose overflow is undefined; the OpenCL compilers it meets (LLVM: verified in both gfx950 code objects of the
+// reference kernel built by this image's clang 22 / ROCm 7.2, tests/test_reference_strict_gpu.py) test the un-squared index
+// instead, so a square that wraps to 0 leaves the seed 0 - and every random number of that path 0.  Bit parity with the
+// compiled reference is the contract, so this follows the compiler, not the source text.
 __device__ __forceinline__ int lcg_seed(uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration)
 {
     const uint32_t index = gx + gy * w + iteration * w * h;
