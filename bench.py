@@ -296,9 +296,11 @@ def committed_pmc(args, W, H, D, B):
     run, summarised by tools/summarize_pmc.py), committed as profiles/r03_pmc_<scene>_<arithmetic>.json.  bench.py itself
     cannot read PMC counters; the file is used only for the configuration AND the kernel source it was measured on."""
     path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.scene}_{args.arithmetic}.json")
-    if not os.path.exists(path) or (W, H, D, args.kernel) != (1920, 1080, 10, "wavefront"):
+    if not os.path.exists(path) or args.kernel != "wavefront":
         return None
     pmc = json.load(open(path))
+    if pmc.get("_config") != {"scene": args.scene, "width": W, "height": H, "depth": D, "arithmetic": args.arithmetic}:
+        return None
     if pmc.get("_spp_per_launch") != min(B, 32):  # counters are per launch: only comparable at the same launch size
         return None
     if pmc.get("_kernel_source_digest") != kernel_source_digest():

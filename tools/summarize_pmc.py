@@ -21,6 +21,14 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 out["_kernel_source_digest"] = bench.kernel_source_digest()
+# ... and the workload: bench.py's defaults unless the pass was given other flags
+import re
+cfg = {"scene": "tris1m", "width": 1920, "height": 1080, "depth": 10, "arithmetic": "default"}
+for key in cfg:
+    m = re.search(r"--%s[ =](\S+)" % key, extra)
+    if m:
+        cfg[key] = m.group(1) if key in ("scene", "arithmetic") else int(m.group(1))
+out["_config"] = cfg
 out["_note"] = ("rocprofv3 --pmc <one group per run> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 "
                 "--no-cpu-baseline --no-boundary " + extra + " (32 spp per launch, 1080p); per-launch means of "
                 "render_wavefront_kernel; FETCH_SIZE/WRITE_SIZE in KB; GRBM_GUI_ACTIVE summed over the 8 XCDs")
