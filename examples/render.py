@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--strict-arithmetic", action="store_true",
+                    help="the strict arithmetic instead of the reference's own build's (both bit-exact modes, DESIGN.md 2)")
     ap.add_argument("-o", "--output", default="render.bmp")
     args = ap.parse_args()
 
@@ -37,7 +39,8 @@ def main():
     else:
         scene = pt.scenes.build(args.scene, w, h)
     scene = pt.bvh_create(scene)
-    be = pt.Backend().setup_context(w, h, args.depth, scene.lightsSize, pt.structs.JITTERED, device=args.device)
+    flags = 0 if args.strict_arithmetic else pt.backend.FLAG_DEFAULT_ARITHMETIC  # default: the reference kernel's own pixels
+    be = pt.Backend().setup_context(w, h, args.depth, scene.lightsSize, pt.structs.JITTERED, device=args.device, flags=flags)
     be.initialize_memory(scene)
     t0 = time.time()
     be.render(0, args.spp)
