@@ -35,7 +35,8 @@ def _worker(rank, world, port, out_path):
     from opencl_pathtracer_amd.distributed import FusedAccumulators, shard_iterations, reduce_statistics
     sc = bvh_create(scenes.cornell_box(W, H))
     first, n = shard_iterations(0, SPP, rank, world)
-    color, count, (dep, bbx, tri), _ = O.oracle_render(sc, W, H, D, n, first_iteration=first, n_threads=2)
+    # (the arithmetic bench.py renders in by default: the reference's own build's)
+    color, count, (dep, bbx, tri), _ = O.oracle_render(sc, W, H, D, n, first_iteration=first, n_threads=2, default_arithmetic=True)
     fb = FusedAccumulators(W, H, torch.device("cpu"))
     fb.color.copy_(torch.from_numpy(color.reshape(-1)))
     fb.count.copy_(torch.from_numpy(count.reshape(-1)))
@@ -56,7 +57,7 @@ def test_two_rank_spp_shards_reduce_to_the_single_rank_image(built, tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = np.load(out)
     sc = bvh_create(scenes.cornell_box(W, H))
-    color, count, (dep, _, _), _ = O.oracle_render(sc, W, H, D, SPP)
+    color, count, (dep, _, _), _ = O.oracle_render(sc, W, H, D, SPP, default_arithmetic=True)
     assert np.array_equal(got["count"], count) and np.array_equal(got["depths"], dep)
     # same samples, only the fp32 summation order differs: (r0+..+r4) + (r5+..+r9) vs sequential
     assert np.allclose(got["color"], color, rtol=2e-6, atol=1e-6)

@@ -14,6 +14,6 @@ for n in $want; do case $n in
   config0) run config0_cornell_512_d4_64spp --scene cornell --width 512 --height 512 --depth 4 --steps 4 --warmup 0 --cpu-spp 64 --cpu-rows 512;;
   config1) run config1_cornell_1080p_d8_1024spp --scene cornell --depth 8 --steps 64 --warmup 0;;
   config2) run config2_tris1m_1080p_d10_256spp --steps 16 --warmup 0;;
-  config4) run config4_standin_matmix_4k_d16 --scene matmix --width 3840 --height 2160 --depth 16 --steps 4 --warmup 1;;
+  config4) run config4_standin_matmix_4k_d16 --scene matmix --width 3840 --height 2160 --depth 16 --spp-per-step 25 --steps 4 --warmup 1;;
   tris4m)  run tris4m_1080p_d10 --scene tris4m --steps 4 --warmup 1;;
 esac; done

@@ -14,7 +14,7 @@ cp gpurun_out/${TAG}_valu_cost_model.json profiles/r03_valu_cost_model_tris1m_de
 python bench.py --steps 10 --warmup 2 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python bench.py --steps 10 --warmup 2 --arithmetic strict --no-cpu-baseline --no-boundary > gpurun_out/${TAG}_bench_strict.json 2> gpurun_out/${TAG}_bench_strict.err
 # BASELINE configs[4]'s stand-in: PMC passes + scheduler statistics + the bench line
-MM="--scene matmix --width 3840 --height 2160 --depth 16"
+MM="--scene matmix --width 3840 --height 2160 --depth 16 --spp-per-step 25"   # (25: the most a 4K launch takes, so one step = one launch)
 bash tools/profile_round.sh ${TAG}_matmix --no-reference-kernel $MM > gpurun_out/profile_round_${TAG}_matmix.log 2>&1
 python bench.py --steps 3 --warmup 1 --scheduler-stats --no-cpu-baseline --no-boundary --no-reference-kernel $MM > gpurun_out/${TAG}_bench_scheduler_stats_matmix.json 2> gpurun_out/${TAG}_bench_scheduler_stats_matmix.err
 python tools/valu_cost_model.py gpurun_out/${TAG}_bench_scheduler_stats_matmix.json gpurun_out/pmc_${TAG}_matmix.json --general > gpurun_out/${TAG}_valu_cost_model_matmix.json 2>> gpurun_out/${TAG}_valu_cost_model.err

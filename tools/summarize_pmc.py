@@ -15,7 +15,8 @@ for name, per_dispatch in acc.items():
     v = list(per_dispatch.values())[1:] or list(per_dispatch.values())  # drop the warm-up launch
     out[name] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
 extra = sys.argv[2] if len(sys.argv) > 2 else ""
-out["_spp_per_launch"] = 32  # bench.py's default --spp-per-step = one launch of 32 iterations per step
+m_spp = __import__("re").search(r"--spp-per-step[ =](\d+)", extra)
+out["_spp_per_launch"] = int(m_spp.group(1)) if m_spp else 32  # bench.py's --spp-per-step (default 32) = ONE launch per step
 # the kernel source these counters were taken on: bench.py quotes them only for that very source (bench.kernel_source_digest)
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
