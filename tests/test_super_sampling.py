@@ -104,6 +104,26 @@ def test_super_sampling_bit_exact_vs_oracle(name, w, h, d, sampler, scene_factor
 
 
 @pytest.mark.gpu
+def test_super_sampling_bit_exact_vs_reference_default_build(scene_factory):
+    """The reference kernel built -D SUPER_SAMPLING as its own build line builds it, 32 iterations: with the JITTERED sampler every
+    work-item owns its pixel, so the adaptive render is deterministic - and in the default-arithmetic mode the integrator makes
+    the same stop decisions, sample for sample: image, sample counts (the sampling density map) and depth histogram are EQUAL."""
+    from opencl_pathtracer_amd import backend
+    case = "cornell_64x48_d4_ss"
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present")
+    sc = scene_factory("cornell", 64, 48)
+    n = 32
+    r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, 64, 48, 4, n)
+    color, count, (dep, bbx, tri), _ = render_scene(sc, 64, 48, 4, n, super_sampling=True, flags=backend.FLAG_DEFAULT_ARITHMETIC)
+    assert count.min() < n  # (pixels were skipped)
+    assert np.array_equal(count, r_count) and np.array_equal(dep, r_dep) and np.array_equal(bbx, r_bbx) and np.array_equal(tri, r_tri)
+    assert np.array_equal(color.view(np.uint32), r_color.view(np.uint32))
+    o_color, o_count, _, _ = O.oracle_render(sc, 64, 48, 4, n, super_sampling=True, default_arithmetic=True)
+    assert np.array_equal(o_count, r_count) and np.array_equal(o_color.view(np.uint32), r_color.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_super_sampling_vs_reference_kernel(scene_factory):
     """The reference kernel built with -D SUPER_SAMPLING: same sampling density map (statistically) and image."""
     case = "cornell_64x48_d4_ss"
