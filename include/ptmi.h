@@ -79,6 +79,12 @@ typedef struct ptmi_config {
                                          whose largest transfer component / (bounce - 5) is below 1 draws a random number, ends unless it
                                          exceeds that coefficient, and has its transfer divided by it.  Images differ from the reference's. */
 
+#define PTMI_FLAG_SOURCE_SEED 32u /* NON-PARITY mode: InitializeRandomSeed as its SOURCE reads under wrapping arithmetic (header.cl:255-264:
+                                    `seed *= 2011; seed *= seed; if(seed == 0) seed = 1;`).  The compiled reference tests the un-squared index
+                                    instead (the square overflows a signed int: undefined, and LLVM folds the test), so a path whose index is a
+                                    non-zero multiple of 2^16 keeps seed 0 and draws 0 for every random number - one path in 65536, the same
+                                    pixels every 2^16 / gcd(2^16, W*H) iterations.  Parity modes reproduce that; this flag gives those paths
+                                    seed 1, as the source intends.  Images differ from the reference's at those pixels only. */
 #define PTMI_FLAG_DEFAULT_ARITHMETIC 16u /* The arithmetic of the build the reference's own build line produces (OpenCL_BuildOptions,
                                          OpenCL.cpp:292-314, passes no floating-point option): a*b+c written in one expression is one
                                          fused multiply-add, a/b goes through v_rcp_f32 of the divisor's mantissa (2.5 ulp), sqrt is

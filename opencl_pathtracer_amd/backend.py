@@ -92,6 +92,7 @@ FLAG_RUSSIAN_ROULETTE = 8  # non-parity mode: the reference's commented-out term
 # the arithmetic of the build the reference's own build line gives (OpenCL default: fused a*b+c, v_rcp_f32 division, v_sqrt_f32);
 # without it the strict arithmetic (-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt).  Both bit for bit.
 FLAG_DEFAULT_ARITHMETIC = 16
+FLAG_SOURCE_SEED = 32  # non-parity mode: seed 1 (as the source text reads) where the compiled reference keeps seed 0 (1 path in 65536)
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",

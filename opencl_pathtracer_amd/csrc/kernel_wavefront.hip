@@ -141,6 +141,7 @@ struct DWarm {
     uint32_t boxes_ordered;
     uint32_t wide_records;  // the record array is 4 GB or more: 64-bit addressing
     uint32_t russian_roulette;  // PTMI_FLAG_RUSSIAN_ROULETTE (non-parity mode)
+    uint32_t source_seed;       // PTMI_FLAG_SOURCE_SEED (non-parity mode)
     uint32_t wait_debt;         // see PTMI_WF_WAIT_DEBT
 };
 
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
             const uint32_t it_local = slot / n_pixels, pixel = slot - it_local * n_pixels;
             const uint32_t gy = pixel / sc.width, gx = pixel - gy * sc.width;
             const uint32_t it = first_iteration + it_local * iteration_stride;
-            int seed0 = lcg_seed(gx, gy, sc.width, sc.height, it);
+            int seed0 = lcg_seed(gx, gy, sc.width, sc.height, it, sc.source_seed != 0);
             float sample_x, sample_y;
             draw_sample(sc, gx, gy, it, seed0, sample_x, sample_y);
             const uint32_t off = sample_pixel(sc, sample_x, sample_y);
@@ -803,7 +804,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
             if (got_job) {
                 const uint32_t it = first_iteration + it_local * iteration_stride;
                 slot = it_local * (sc.width * sc.height) + gy * sc.width + gx;
-                seed = lcg_seed(gx, gy, sc.width, sc.height, it);
+                seed = lcg_seed(gx, gy, sc.width, sc.height, it, sc.source_seed != 0);
                 float sample_x, sample_y;
                 draw_sample(sc, gx, gy, it, seed, sample_x, sample_y);
                 check(sample_x >= -0.5f && sample_y >= -0.5f && sample_x <= 0.5f && sample_y <= 0.5f, C_CHK_SAMPLE);  // cl:1217
@@ -1056,6 +1057,7 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         warm.boxes_ordered = sc.boxes_ordered;
         warm.wide_records = sc.wide_records;
         warm.russian_roulette = sc.russian_roulette;
+        warm.source_seed = sc.source_seed;
         const bool plain = sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette &&
                            sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats;
         warm.wait_debt = lv >= 16u ? 768u : (plain ? 320u : 512u);  // (the cheaper a path-logic pass, the sooner it pays)

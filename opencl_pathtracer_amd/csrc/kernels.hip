@@ -94,7 +94,7 @@ __device__ __forceinline__ V4 trace_path(const DScene& sc, uint32_t gx, uint32_t
                                          uint32_t* __restrict__ stack, float& sample_x, float& sample_y,
                                          uint32_t& depth, uint32_t& segments, uint32_t& shadows, PathCounters& pc)
 {
-    int seed = lcg_seed(gx, gy, sc.width, sc.height, iteration);
+    int seed = lcg_seed(gx, gy, sc.width, sc.height, iteration, sc.source_seed != 0);
     draw_sample(sc, gx, gy, iteration, seed, sample_x, sample_y);
 
     Ray r;

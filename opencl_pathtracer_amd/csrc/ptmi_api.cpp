@@ -506,6 +506,7 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     ds.n_lights = ctx->cfg.lights_size;
     ds.sampler = ctx->cfg.sampler;
     ds.russian_roulette = (ctx->cfg.flags & PTMI_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u;
+    ds.source_seed = (ctx->cfg.flags & PTMI_FLAG_SOURCE_SEED) ? 1u : 0u;
     HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
     return PTMI_OK;
 }

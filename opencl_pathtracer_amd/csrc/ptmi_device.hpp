@@ -198,12 +198,13 @@ __device__ __forceinline__ float lcg_random(int& seed)
 // reference kernel built by this image's clang 22 / ROCm 7.2, tests/test_reference_strict_gpu.py) test the un-squared index
 // instead, so a square that wraps to 0 leaves the seed 0 - and every random number of that path 0.  Bit parity with the
 // compiled reference is the contract, so this follows the compiler, not the source text.
-__device__ __forceinline__ int lcg_seed(uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration)
+// `source_rule` (PTMI_FLAG_SOURCE_SEED, non-parity): the test as the source text reads under wrapping arithmetic - on the square.
+__device__ __forceinline__ int lcg_seed(uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, uint32_t iteration, bool source_rule = false)
 {
     const uint32_t index = gx + gy * w + iteration * w * h;
     uint32_t s = index * 2011u;
     s *= s;
-    return (int)(index == 0u ? 1u : s);
+    return (int)((source_rule ? s == 0u : index == 0u) ? 1u : s);
 }
 
 // Vector_PutInSameHemisphereAs, header.cl:237-244

@@ -142,6 +142,7 @@ struct DScene {
     uint32_t wide_records;     // that array is 4 GB or more: byte offsets need 64 bits
     uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)
     uint32_t russian_roulette; // PTMI_FLAG_RUSSIAN_ROULETTE
+    uint32_t source_seed;      // PTMI_FLAG_SOURCE_SEED
 };
 
 // The integrator's device code exists once per ARITHMETIC MODE (ptmi_device.hpp: strict / the reference's default OpenCL

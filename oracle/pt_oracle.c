@@ -887,6 +887,7 @@ static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint3
     ray_t r;
     int32_t seed = pto_initialize_random_seed(gx, gy, sc->image_width, sc->image_height, iteration);
     float sample[2];
+    if (sc->source_seed && seed == 0) seed = 1; /* non-parity mode: the zero test where the source text has it, on the square */
     f4 shot, radiance = mk4(0, 0, 0, 0), transfer = mk4(1, 1, 1, 1);
     int active = 1, n_trace = 0;
 

@@ -57,6 +57,7 @@ typedef struct pto_scene {
     uint32_t super_sampling;
     const float* x2inv;     /* 1001-entry table (Kernel/X2inv.cl), only if super_sampling */
     uint32_t russian_roulette; /* the block the reference keeps commented out (cl:1306-1314, RUSSIAN_ROULETTE false): non-parity mode */
+    uint32_t source_seed;      /* non-parity mode: InitializeRandomSeed's zero test on the SQUARE, as the source reads (h:255-264) */
 } pto_scene;
 
 /* Output buffers, caller-allocated; accumulated into (not zeroed here). */

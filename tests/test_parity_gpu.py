@@ -161,6 +161,23 @@ def test_russian_roulette_mode_vs_oracle(kernel, scene_factory):
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
+def test_source_seed_mode_vs_oracle(kernel, scene_factory):
+    """PTMI_FLAG_SOURCE_SEED: InitializeRandomSeed's zero test where the source text has it (on the square) - a non-parity mode.
+    96 x 96: index = x + 96 y + 9216 it is a multiple of 2^16 for pixel (64, 42) at iteration 28: the compiled reference (and the
+    parity modes) keep seed 0 there and draw 0 for every random number; with the flag that path gets seed 1.  Every other pixel of
+    the iteration is untouched; bit-exact against the oracle's same switch."""
+    w, h, d = 96, 96, 8
+    sc = scene_factory("matmix", w, h)
+    flags = KERNELS[kernel] | backend_flags.FLAG_SOURCE_SEED
+    color, count, _, counters = render_scene(sc, w, h, d, 1, first_iteration=28, flags=flags)
+    o_color, o_count, _, totals = O.oracle_render(sc, w, h, d, 1, first_iteration=28, source_seed=True)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count) and counters == totals
+    parity, _, _, _ = render_scene(sc, w, h, d, 1, first_iteration=28, flags=KERNELS[kernel])
+    differs = np.argwhere((color.view(np.uint32) != parity.view(np.uint32)).any(-1))
+    assert differs.tolist() == [[42, 64]]
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 def test_leaf_without_triangles_next_to_a_leaf(kernel, scene_factory):
     """A hand-made tree the product builder never emits: a leaf with nbTriangles == 0 whose box is NOT flagged isEmpty,
     sibling of an ordinary leaf.  The reference descends into it (its leaf loop runs zero times, FullKernel.cl:638-646)
