@@ -54,7 +54,7 @@ def test_example_renderer_writes_the_bmp_the_host_path_would(tmp_path, scene_fac
     assert r.returncode == 0, r.stderr
     assert "Msamples/s" in r.stdout
     sc = scene_factory("cornell", 50, 38)
-    color, count, _, _ = O.oracle_render(sc, 50, 38, 4, 6)
+    color, count, _, _ = O.oracle_render(sc, 50, 38, 4, 6, default_arithmetic=True)  # (the example renders the reference's own pixels)
     want = tmp_path / "want.bmp"
     output.save_bmp(str(want), color, count)
     assert out.read_bytes() == want.read_bytes()

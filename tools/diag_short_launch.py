@@ -6,7 +6,8 @@ import time
 sys.path[:0] = [".", "tests"]
 import opencl_pathtracer_amd as pt
 
-W, H, D = 1920, 1080, 10
+import os
+W, H, D = 1920, 1080, int(os.environ.get("DEPTH", "10"))  # DEPTH=1: every path one segment long - a launch without a ragged end
 sc = pt.bvh_create(pt.scenes.build("tris1m", W, H))
 be = pt.Backend().setup_context(W, H, D, sc.lightsSize, flags=pt.backend.FLAG_DEFAULT_ARITHMETIC)
 be.initialize_memory(sc)
