@@ -64,9 +64,11 @@ typedef struct ptmi_config {
     /* Multi-GPU render (the reference drives devices[0] only, OpenCL.cpp:363-366): n_devices > 1 replicates the scene on
      * devices[0..n_devices) and spreads the iteration ids of every ptmi_render call over them (device k takes the ids
      * congruent to k modulo n_devices: the same id set as a single-device render, so the same samples); devices[0] is
-     * the one ptmi_read_image / ptmi_read_snapshot sum the partial accumulators on (peer copies over xGMI + one add
-     * kernel, in device order).  n_devices 0 or 1 = single device `device`.  A device may be listed more than once
-     * (used by the tests on a one-GPU box). */
+     * the one the partial accumulators are summed on: ptmi_read_image / ptmi_read_display by an ncclReduce over xGMI
+     * (librccl, loaded at run time; environment PTMI_REDUCE=peer forces the fallback), ptmi_read_snapshot - the per-image
+     * loop, where one device's share changes per image - by one peer copy of that share + one add kernel in device order
+     * (also the fallback where RCCL is absent or refuses the device list).  n_devices 0 or 1 = single device `device`.
+     * A device may be listed more than once (used by the tests on a one-GPU box; RCCL refuses that, the fallback runs). */
     uint32_t n_devices;
     int32_t devices[PTMI_MAX_DEVICES];
 } ptmi_config;
