@@ -167,6 +167,10 @@ def test_random_sampler_vs_reference_default_build(scene_factory):
     # the paths themselves are the reference's, exactly: histograms are atomic in the reference too
     assert np.array_equal(dep, r_dep) and np.array_equal(bbx, r_bbx) and np.array_equal(tri, r_tri)
     assert (r_count <= count).all() and r_count.sum() >= 0.97 * count.sum()
-    same = r_count == count  # pixels where the reference lost nothing: the same samples, summed in another order
-    assert same.mean() > 0.8  # (measured: 89 % of the pixels after 8 iterations)
-    assert np.allclose(color[same], r_color[same], rtol=1e-5, atol=1e-5)
+    same = r_count == count  # pixels where the reference lost no count (measured: 89 % of them after 8 iterations)
+    assert same.mean() > 0.8
+    # the sums: the colour and the count of a pixel are separate read-modify-writes in the reference, so it can lose either;
+    # radiance is non-negative, so what it keeps never exceeds the atomic sum, and most pixels keep everything
+    assert (r_color[..., :3] <= color[..., :3] * (1 + 1e-5) + 1e-5).all()
+    close = np.isclose(color, r_color, rtol=1e-5, atol=1e-5).all(-1)
+    assert close[same].mean() > 0.75 and close.mean() > 0.6  # (measured: 0.85 and 0.76; the race decides)
