@@ -268,6 +268,12 @@ def main():
                 out["vs_baseline"] = ref["ratio_at_the_integrators_launch_size"]
                 out["vs_baseline_note"] = ("value / the reference's own OpenCL kernel (unmodified source, its own build options, 8x8 "
                                            "work-groups) timed on this GPU in this run on the same workload; BASELINE.md holds no published number")
+        if "boundary" in out and "Mpaths/s" in out.get("reference_kernel", {}):
+            # the per-image protocol as the shim serves it (16 images share a launch, EVERY image read back and shown) against
+            # the reference kernel's bare launches (no readback): what a caller of the reference API gets
+            seg_per_path = out["segments_per_path"]
+            out["reference_kernel"]["ratio_per_image_protocol_shim_default"] = (
+                out["boundary"]["per_image_burst16_Msamples/s"] / seg_per_path / out["reference_kernel"]["Mpaths/s"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H, D, args.cpu_rows, args.cpu_spp, args.arithmetic == "default")
         print(json.dumps(out), flush=True)

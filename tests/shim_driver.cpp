@@ -5,6 +5,7 @@
 // scene file: u32 W,H,depth,sampler,nImages, nTri,nLights,nMat,nTex,nTexels; float camPos[4],camDir[4],camRight[4],
 // camUp[4]; Sky; Triangle[nTri]; Light[]; Material[]; Texture[]; Uchar4[]
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <vector>
@@ -51,6 +52,7 @@ int main(int argc, char** argv)
     gv.imageColor = color.data(); gv.imageRayNb = count.data();
     gv.rayDepths = depths.data(); gv.rayIntersectedBBx = bbx.data(); gv.rayIntersectedTri = tri.data();
     double t1 = 0, t2 = 0, t3 = 0;
+    gv.printLogInfos = std::getenv("SHIM_DRIVER_LOG_INFO") != nullptr;  // the reference's -D LOG_INFO switch (OpenCL.cpp:310)
     try {
         BVH_Create(gv);
         if (gv.bvhMaxDepth >= PTMI_BVH_MAX_DEPTH || gv.lightsSize >= PTMI_MAX_LIGHT_SIZE) return 3;  // PathTracer.cpp:54-65

@@ -108,6 +108,27 @@ def test_shim_end_to_end_matches_oracle(name, w, h, d, sampler, n, strict, drive
     assert np.array_equal(dep, o_dep) and np.array_equal(bbx, o_bbx) and np.array_equal(tri, o_tri)
 
 
+@pytest.mark.gpu
+def test_shim_log_info_counts_the_reference_device_checks(driver, tmp_path):
+    """globalVars.printLogInfos = the reference's -D LOG_INFO (OpenCL.cpp:310), which makes ITS kernel check its invariants on the
+    device and print a line per failure (header.cl:21-48).  Over the shim the same switch runs the kernel instantiation that
+    counts those failures; the totals are reported after the render (all zero for a healthy scene) and the image is unchanged."""
+    name, w, h, d, n = "matmix", 96, 96, 8, 3
+    sc = scenes.build(name, w, h)
+    scene_file, out_file = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
+    dump_scene(scene_file, sc, w, h, d, S.JITTERED, n)
+    r = subprocess.run([driver, scene_file, out_file], capture_output=True, text=True, env={**os.environ, "SHIM_DRIVER_LOG_INFO": "1"})
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stderr.splitlines() if "device-side checks" in l]
+    assert len(line) == 1, r.stderr
+    assert ("SAMPLER - invalid pixel 0, Kernel_Main incorrect normals 0, incorrect radiance L 0, Vector_PutInSameHemisphereAs 0, "
+            "rayIntersection histogram overflow 0") in line[0]
+    _, color, count, _, _, _ = read_result(out_file, w, h, d)
+    ref = bvh_create(scenes.build(name, w, h))
+    o_color, o_count, _, _ = O.oracle_render(ref, w, h, d, n, default_arithmetic=True)
+    assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32)) and np.array_equal(count, o_count)
+
+
 # ---- the reference's own orchestration over the shim ----------------------------------------------------------------
 # oracle/_ref/ref_main_driver (oracle/Makefile: ref-main) = the reference's Controleur/PathTracer.cpp and
 # PathTracer_Importer.cpp compiled UNMODIFIED + csrc/PathTracer_HIP.cpp built against the reference's own headers +
