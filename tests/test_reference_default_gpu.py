@@ -130,6 +130,20 @@ def test_full_size_bit_exact_vs_reference_default_build(case):
     _assert_equal_to_reference(render_scene(sc, w, h, d, spp, sampler=sampler, flags=DA), ref, case)
 
 
+def test_four_million_triangles_bit_exact_vs_reference_default_build():
+    """A tree of depth 24 (4M random triangles, 427 MB of records: four workgroups per CU instead of five, leaves and nodes far
+    beyond the L2s) through the same comparison: the reference's code object is specialised on sampler, image size, ray depth and
+    light count only, so the 1M-triangle configuration's kernel renders this scene too.  1920x1080, 1 spp."""
+    case = "tris1m_1920x1080_d10"
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+    w, h, d = 1920, 1080, 10
+    sc = bvh_create(scenes.build("tris4m", w, h))
+    assert sc.bvhMaxDepth >= 23
+    ref = O.ref_gpu_render(case, sc, w, h, d, 1)
+    _assert_equal_to_reference(render_scene(sc, w, h, d, 1, flags=DA), ref, "tris4m")
+
+
 @pytest.mark.parametrize("case", ["cornell_64x48_d4", "cornell_64x48_d4_uni", "matmix_96x96_d8", "tris20k_96x64_d6"])
 def test_default_arithmetic_hip_equals_oracle(case, scene_factory):
     """HIP (wavefront and one-path-per-lane kernels) == the oracle's default-arithmetic build, bit for bit - the oracle's
