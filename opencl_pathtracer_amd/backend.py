@@ -96,7 +96,7 @@ FLAG_SOURCE_SEED = 32  # non-parity mode: seed 1 (as the source text reads) wher
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats", "ptmi_get_invariant_checks",
+               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats", "ptmi_get_invariant_checks", "ptmi_literal_kernel_reason",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
@@ -136,6 +136,8 @@ def load_library():
     lib.ptmi_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.ptmi_get_scheduler_stats.argtypes = [vp, C.POINTER(SchedulerStats)]
     lib.ptmi_get_invariant_checks.argtypes = [vp, C.POINTER(InvariantChecks)]
+    lib.ptmi_literal_kernel_reason.argtypes = [vp]
+    lib.ptmi_literal_kernel_reason.restype = C.c_char_p
     lib.ptmi_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
     lib.ptmi_set_stream.argtypes = [vp, vp]
     lib.ptmi_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
@@ -322,6 +324,12 @@ class Backend:
         s = InvariantChecks()
         self._check(self._lib.ptmi_get_invariant_checks(self._ctx, C.byref(s)))
         return s.as_dict()
+
+    def literal_kernel_reason(self):
+        """None, or why the uploaded scene is rendered by the one-path-per-lane kernel (records on which the reference's
+        triangle test yields NaN distances: ptmi.h)."""
+        r = self._lib.ptmi_literal_kernel_reason(self._ctx)
+        return r.decode() if r else None
 
     def kernel_time(self):
         """(total_ms, launches) of the integrator kernel since the last call (HIP events on its stream)."""

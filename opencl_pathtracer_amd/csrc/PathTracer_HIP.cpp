@@ -169,6 +169,9 @@ void OpenCL_InitializeMemory(GlobalVars& globalVars)
     sc.camera_up = *reinterpret_cast<const ptmi_float4*>(&globalVars.cameraUp);
     const int rc = ptmi_initialize_memory(g_ctx, &sc);
     if (rc) fail("OpenCL_InitializeMemory", rc);
+    if (const char* why = ptmi_literal_kernel_reason(g_ctx))
+        std::fprintf(stderr, "[ptmi] note: %s: the reference's triangle test yields NaN distances there, so the scene is rendered by the "
+                             "one-path-per-lane kernel (the reference's images bit for bit, but slower than the wavefront kernel)\n", why);
 }
 
 // What the reference prints line by line from its kernel with -D LOG_INFO, as totals after the render (only in that mode)

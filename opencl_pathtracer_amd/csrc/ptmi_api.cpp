@@ -93,6 +93,9 @@ struct ptmi_ctx {
     std::string err;
     uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     uint32_t iterations_per_launch = kMaxIterationsPerLaunch;
+    // Why the uploaded scene is rendered by the one-path-per-lane kernel although the context did not ask for it (empty: it is
+    // not).  See scene_needs_literal_kernel().
+    std::string literal_kernel_reason;
 
     // RCCL communicators, one per device of the context (single process, ncclCommInitAll): the sum of the devices' partial
     // images is an ncclReduce over xGMI where librccl is present and the devices are distinct (rccl_reduce_snapshots)
@@ -117,6 +120,9 @@ namespace {
 // the integrator's entry points in the context's arithmetic mode (ptmi_internal.h)
 bool default_arithmetic(const ptmi_ctx* ctx) { return (ctx->cfg.flags & PTMI_FLAG_DEFAULT_ARITHMETIC) != 0; }
 #define KERNELS_OF(ctx, name) (default_arithmetic(ctx) ? name##_da : name)
+
+// one path per lane (kernels.hip) instead of the wavefront kernel: asked for, or needed by the scene
+bool one_path_per_lane(const ptmi_ctx* ctx) { return (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0 || !ctx->literal_kernel_reason.empty(); }
 
 int fail(ptmi_ctx* ctx, int code, const std::string& msg)
 {
@@ -178,6 +184,7 @@ void free_scene_memory(ptmi_ctx* ctx)
     ctx->display_bytes = 0;
     ctx->accum_bound = false;
     ctx->have_scene = false;
+    ctx->literal_kernel_reason.clear();
 }
 
 template <class T>
@@ -219,6 +226,7 @@ struct Relayout {
     bool tris_precomputed = false;
     bool plain_shading = false; // every material a plain-colour MAT_STANDART, every light a LIGHT_POINT
     bool boxes_ordered = true;  // all non-empty child boxes finite with pMin <= pMax
+    std::string literal_kernel_reason;  // scene_needs_literal_kernel()
     uint32_t root_ref = 0;
     uint32_t max_depth = 0;
 };
@@ -228,6 +236,51 @@ bool texture_ok(const ptmi_texture& t, uint32_t data_size)
     if (t.width == 0 || t.height == 0) return false;
     const uint64_t end = (uint64_t)t.offset + (uint64_t)t.width * t.height;
     return end <= data_size;
+}
+
+// Can a NaN reach a query's limit in this scene?  The reference's triangle test rejects with comparisons only
+// (FullKernel.cl:533-567), so a triangle whose test produces NaNs - a zero-area triangle as the importer emits it: N =
+// normalize(0) = 0/0 (Utils.h:144) - is ACCEPTED by every ray that reaches it, with a NaN squared distance: from then on
+// nothing is "too far" (:543, :92) and the LAST triangle that passes the remaining tests wins, whatever its distance.  The
+// one-path-per-lane kernel runs the reference's loops literally and reproduces this bit for bit.  The wavefront kernel's leaf
+// passes test the triangles of a leaf side by side and keep the minimum of (distance, order) keys - the same result as the
+// sequential loop only while distances are ordered, i.e. not NaN.  So a scene in which a NaN distance CAN occur is rendered
+// by the one-path-per-lane kernel (tests/test_reference_default_gpu.py::test_fuzzed_scenes...).  It cannot occur when
+//   * every triangle's vertices, normals and vertex normals, the lights' positions and directions and the camera are finite
+//     and at most 2^21 (normals: 16) in magnitude: then no product of the test overflows (ray parameter <= 2^48, barycentric
+//     numerators <= 2^119) and inf - inf / 0 * inf never forms, and
+//   * the barycentric determinant uv^2 - uu.vv of every triangle is non-zero with a finite reciprocal, in both arithmetics:
+//     then s and t are numbers, an accepted hit lies inside its triangle, and the next ray starts within the same bounds.
+// Returns the reason, or an empty string.
+std::string scene_needs_literal_kernel(const ptmi_scene* sc)
+{
+    constexpr float kCoord = 2097152.0f, kNormal = 16.0f;
+    auto ok = [](const ptmi_float4& v, float bound) {
+        return std::fabs(v.x) <= bound && std::fabs(v.y) <= bound && std::fabs(v.z) <= bound && std::fabs(v.w) <= bound;  // (false for NaN)
+    };
+    if (!ok(sc->camera_position, kCoord) || !ok(sc->camera_direction, kCoord) || !ok(sc->camera_right, kCoord) || !ok(sc->camera_up, kCoord))
+        return "the camera is not finite (or beyond 2^21)";
+    for (uint32_t i = 0; i < sc->lights_size; i++)
+        if (!ok(sc->lights[i].position, kCoord) || !ok(sc->lights[i].direction, kCoord))
+            return "light " + std::to_string(i) + " is not finite (or beyond 2^21)";
+    auto dot4 = [](const float a[4], const float b[4]) {
+        return std::fmaf(a[3], b[3], std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])));
+    };
+    for (uint32_t i = 0; i < sc->triangulation_size; i++) {
+        const ptmi_triangle& t = sc->triangulation[i];
+        if (!ok(t.s1, kCoord) || !ok(t.s2, kCoord) || !ok(t.s3, kCoord))
+            return "triangle " + std::to_string(i) + " has a vertex that is not finite (or beyond 2^21)";
+        if (!ok(t.n, kNormal) || !ok(t.n1, kNormal) || !ok(t.n2, kNormal) || !ok(t.n3, kNormal))
+            return "triangle " + std::to_string(i) + " has a normal that is not finite (a zero-area triangle of the importer: N = 0/0)";
+        const float u[4] = {t.s2.x - t.s1.x, t.s2.y - t.s1.y, t.s2.z - t.s1.z, t.s2.w - t.s1.w};
+        const float v[4] = {t.s3.x - t.s1.x, t.s3.y - t.s1.y, t.s3.z - t.s1.z, t.s3.w - t.s1.w};
+        const float uv = dot4(u, v), uu = dot4(u, u), vv = dot4(v, v);
+        const float det[2] = {uv * uv - uu * vv, std::fmaf(uv, uv, -(uu * vv))};  // cl:556, strict and default arithmetic
+        for (float d : det)
+            if (!(d != 0.0f) || !std::isfinite(d) || !std::isfinite(1.0f / d))
+                return "triangle " + std::to_string(i) + " has no area (its barycentric determinant is zero or not finite)";
+    }
+    return std::string();
 }
 
 int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
@@ -288,6 +341,8 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         s.mat_pos = t.mat_pos;
         s.mat_neg = t.mat_neg;
     }
+
+    out.literal_kernel_reason = scene_needs_literal_kernel(sc);
 
     // Ray-independent part of the triangle test, if every triangle keeps the importers' convention of equal w
     // on its three vertices (then the edge vectors have w = +0 exactly).  Same operations, same order, same
@@ -579,7 +634,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     ON_DEVICE(ctx, d);
     if (d.pending_events.size() >= 512)
         if (int rc = fold_events(ctx, d)) return rc;
-    const bool megakernel = (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0;
+    const bool megakernel = one_path_per_lane(ctx);
     const bool staged = !megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM;
     // alternate launch streams: only where the launch itself neither reads nor writes the accumulators (staged results, no
     // adaptive sampling), on the context's own stream, and unless switched off (PTMI_SERIAL_LAUNCHES: developer A/B switch)
@@ -1014,6 +1069,10 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
 
     Relayout lay;
     if (int rc = build_layout(ctx, sc, lay)) return rc;
+    if (!lay.literal_kernel_reason.empty() && ctx->cfg.super_sampling)
+        return fail(ctx, PTMI_ERR_UNSUPPORTED, "SUPER_SAMPLING needs the wavefront kernel, which cannot reproduce the reference on this scene: " +
+                                                   lay.literal_kernel_reason);
+    ctx->literal_kernel_reason = lay.literal_kernel_reason;
     // a ray holds at most one pending far child per level it has descended
     ctx->stack_levels = lay.max_depth < 1 ? 1 : lay.max_depth;
     for (DeviceState& d : ctx->dev)
@@ -1077,6 +1136,13 @@ int ptmi_render_snapshots(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_it
     if (ctx->cfg.super_sampling || ctx->cfg.sampler == PTMI_SAMPLER_RANDOM || (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL))
         return fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_render_snapshots needs staged launches (JITTERED / UNIFORM sampler, wavefront kernel, no "
                                                 "super_sampling): call ptmi_render + ptmi_snapshot per iteration instead");
+    if (one_path_per_lane(ctx)) {  // a scene that needs the one-path-per-lane kernel: the same images, one launch each
+        for (uint32_t k = 0; k < n_iterations; k++) {
+            if (int rc = ptmi_render(ctx, first_iteration + k, 1)) return rc;
+            if (int rc = snapshot_all(ctx, (first_slot + k) % kUserSlots)) return rc;
+        }
+        return PTMI_OK;
+    }
     const uint32_t G = ctx->n_dev();
     for (uint32_t k = 0; k < G; k++) {
         uint32_t first_k, n_k;
@@ -1085,6 +1151,11 @@ int ptmi_render_snapshots(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_it
         if (int rc = render_on_device(ctx, ctx->dev[k], first_k, n_k, G, &plan)) return rc;
     }
     return PTMI_OK;
+}
+
+const char* ptmi_literal_kernel_reason(const ptmi_ctx* ctx)
+{
+    return ctx && ctx->have_scene && !ctx->literal_kernel_reason.empty() ? ctx->literal_kernel_reason.c_str() : nullptr;
 }
 
 int ptmi_synchronize(ptmi_ctx* ctx)

@@ -28,7 +28,7 @@
 //       AMDGPUCodeGenPrepare with denormals enabled); with a CONSTANT divisor the reciprocal of its mantissa is folded at
 //       compile time, i.e. correctly rounded instead of the instruction's value: fdiv(a, DivC);
 //     * sqrt(x) = v_sqrt_f32 behind a 2^32 scaling of denormal inputs.
-//   The platform library (dot, cross, normalize, length's range scaling, sin, cos) is the same code in both modes.
+//   The platform library (dot, cross, normalize, length - bare v_sqrt_f32 included -, sin, cos) is the same code in both modes.
 #ifndef PTMI_DEFAULT_ARITHMETIC
 #define PTMI_DEFAULT_ARITHMETIC 0
 #endif
@@ -99,12 +99,18 @@ __device__ __forceinline__ float fdiv(float a, const DivC& d)
     if (!kDefaultArithmetic) return a / d.c;
     return __builtin_ldexpf(__builtin_amdgcn_frexp_mantf(a) * d.inv_mant, __builtin_amdgcn_frexp_expf(a) - d.exp);
 }
-__device__ __forceinline__ float fsqrt(float x)
+// sqrt(x) where the compiler is NOT asked for the correctly rounded one: v_sqrt_f32 behind a 2^32 scaling of denormal inputs.
+// The default build's sqrt - and the square root inside the platform library's length() in BOTH builds (below).
+__device__ __forceinline__ float approx_sqrt(float x)
 {
-    if (!kDefaultArithmetic) return sqrtf(x);
     const bool tiny = x < 0x1p-126f;
     const float r = __builtin_amdgcn_sqrtf(tiny ? __builtin_ldexpf(x, 32) : x);
     return tiny ? __builtin_ldexpf(r, -16) : r;
+}
+__device__ __forceinline__ float fsqrt(float x)
+{
+    if (!kDefaultArithmetic) return sqrtf(x);
+    return approx_sqrt(x);
 }
 
 // The OpenCL geometric builtins, fixed to the definitions of the OpenCL library the reference meets on
@@ -114,20 +120,21 @@ __device__ __forceinline__ float dot(V4 a, V4 b)
 {
     return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
 }
-// length(float4) of the library (_Z6lengthDv4_f): sqrt(dot) with a rescaling for squared lengths outside the normal range
-// (never taken by a light distance in the strict mode's tests, where the branches only matter for overflow; kept literally
-// in the default mode, whose square root is the instruction)
+// length(float4) of the library (_Z6lengthDv4_f): sqrt(dot) with a rescaling for squared lengths outside the normal range.
+// The same code in both builds of the reference: -cl-fp32-correctly-rounded-divide-sqrt reaches the kernel's own sqrt()
+// calls, not the library's - its square root stays the bare v_sqrt_f32 (ISA of both builds; found by the fuzzed scenes of
+// tests/test_reference_default_gpu.py, where a light on a vertex makes the shadow ray's limit - this length, cl:938 - decide
+// box tests by its last bit).
 __device__ __forceinline__ float length(V4 a)
 {
     const float d = dot(a, a);
-    if (!kDefaultArithmetic) return sqrtf(d);
     if (d < 0x1p-126f) {
         a = a * 0x1p+86f;
-        return fsqrt(dot(a, a)) * 0x1p-86f;
+        return approx_sqrt(dot(a, a)) * 0x1p-86f;
     }
     if (d == INFINITY) {
         a = a * 0x1p-66f;
-        return fsqrt(dot(a, a)) * 0x1p+66f;
+        return approx_sqrt(dot(a, a)) * 0x1p+66f;
     }
     return __builtin_amdgcn_sqrtf(d);
 }

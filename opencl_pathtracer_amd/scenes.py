@@ -17,6 +17,7 @@ and a material/texture/light mix used by the parity tests.  Every scene is a ``S
 the subset of the reference's ``GlobalVars`` (PathTracer_Structs.h:145-189) the device
 backend reads.
 """
+import re
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -539,6 +540,156 @@ def feature_scene(feature, width, height):
                  np.concatenate(texels), sky, pos, d, r, u, name="feat_" + feature)
 
 
+def fuzz_scene(seed, width, height, n_lights=1, hostile=False):
+    """A scene drawn from a seed: nothing in it is arranged to please the integrator.  For the parity tests that run the
+    reference kernel beside the integrator (tests/test_reference_default_gpu.py): whatever the importer's conventions
+    (``triangle_create`` ...) can produce, in proportions no hand-made scene has.
+
+    * 40-300 triangles at scales from 0.02 to 8 around the origin inside a (sometimes missing) box of six big quads:
+      free soup, fans sharing a vertex, slivers, stacks of coplanar and of exactly coincident triangles (distance ties),
+      axis-aligned sheets (flat bounding boxes), one or two smooth spheres;
+    * per-vertex normals: flat, smooth, zero (the importer's fallback to N with w = 1), or tilted far off the face;
+    * 3-9 materials of all five types with colours from 0 to 1.2, opacities from 0 to 1, a third of them textured
+      (odd sizes down to 1x1; uv from -3 to 4, so every wrap is taken), different materials on the two sides;
+    * ``n_lights`` lights of random types, some inside geometry, some far away, power over four decades
+      (the reference bakes the light count into its program: 1 and 3 have code objects under oracle/_ref);
+    * a cube-map sky with random face sizes, rotation, ground scale and exposure factors - or none;
+    * a camera somewhere around, looking near the origin, with an arbitrary (not orthonormal) film frame.
+    ``hostile`` adds what a mesh can hold and the file format carries: zero-area triangles (one point three times, two equal
+    vertices, three collinear ones: N is 0/0, and the reference's test then ACCEPTS them for every ray that reaches them -
+    all its rejections are comparisons, false for a NaN), vertices 1e6 away, a tiny triangle, a light exactly on a vertex.
+    """
+    rs = np.random.RandomState(1000003 * int(seed) + 17 * int(n_lights) + (7 if hostile else 0))  # (any hostile set: the same base scene)
+    U = lambda lo, hi, *shape: rs.uniform(lo, hi, shape).astype(f32) if shape else f32(rs.uniform(lo, hi))
+    texels, textures = [], []
+
+    def add_tex(w, h):
+        img = rs.randint(0, 256, (w * h, 4)).astype(np.uint8)
+        off = sum(len(t) for t in texels)
+        texels.append(img)
+        textures.append((w, h, off))
+        return len(textures) - 1
+
+    if rs.rand() < 0.6:
+        sky = np.zeros((), dtype=S.Sky)
+        a = rs.uniform(0, 2 * np.pi)
+        sky["cosRotationAngle"], sky["sinRotationAngle"] = f32(np.cos(a)), f32(np.sin(a))
+        sky["groundScale"] = U(0.3, 3.0)
+        sky["exposantFactorX"], sky["exposantFactorY"] = (U(0.0, 2.0), U(0.0, 2.0)) if rs.rand() < 0.5 else (f32(0), f32(0))
+        for i in range(6):
+            w, h = int(rs.choice([1, 2, 5, 16, 31])), int(rs.choice([1, 3, 8, 16]))
+            off = sum(len(t) for t in texels)
+            texels.append(rs.randint(0, 256, (w * h, 4)).astype(np.uint8))
+            sky["skyTextures"][i] = (w, h, off)
+    else:
+        sky, t0 = no_sky(tuple(int(v) for v in rs.randint(0, 256, 4)))
+        texels.append(t0)
+
+    n_mat = int(rs.randint(3, 10))
+    mats = []
+    for _ in range(n_mat):
+        mtype = int(rs.choice([S.MAT_STANDART, S.MAT_STANDART, S.MAT_GLASS, S.MAT_WATER, S.MAT_VARNHISHED, S.MAT_METAL]))
+        tex = add_tex(int(rs.choice([1, 2, 3, 7, 17, 32])), int(rs.choice([1, 2, 5, 8, 29]))) if rs.rand() < 0.35 else -1
+        mats.append(material_create(mtype, color=tuple(U(0.0, 1.2, 3)) + (0.0,), texture_id=tex, opacity=float(U(0.0, 1.0))))
+    pick = lambda: int(rs.randint(0, n_mat))
+
+    parts = []
+
+    def add(s, normals_mode=None, n=None):
+        """s: (k,3,3) vertices"""
+        s = np.asarray(s, f32)
+        k = len(s)
+        mode = normals_mode if normals_mode is not None else rs.choice(["flat", "zero", "tilted", "flat"])
+        if mode == "flat":
+            nrm = None
+        elif mode == "zero":
+            nrm = np.zeros((k, 3, 3), f32)
+        elif mode == "given":
+            nrm = n
+        else:
+            c = np.cross(s[:, 1] - s[:, 0], s[:, 2] - s[:, 0])
+            nrm = (c[:, None, :] / np.maximum(np.linalg.norm(c, axis=-1), 1e-30)[:, None, None] + rs.uniform(-0.9, 0.9, (k, 3, 3))).astype(f32)
+        uvp = U(-3.0, 4.0, k, 3, 2)
+        uvn = U(-3.0, 4.0, k, 3, 2) if rs.rand() < 0.5 else uvp
+        parts.append(triangle_create(s[:, 0], s[:, 1], s[:, 2], normals=nrm, uvp=uvp, uvn=uvn, mat_pos=pick(),
+                                     mat_neg=pick() if rs.rand() < 0.5 else None))
+
+    if rs.rand() < 0.7:  # the room
+        L = float(U(4.0, 9.0))
+        c = [(-L, -L, -L), (L, -L, -L), (L, L, -L), (-L, L, -L), (-L, -L, L), (L, -L, L), (L, L, L), (-L, L, L)]
+        for a, b, cc, d in ((0, 1, 2, 3), (4, 7, 6, 5), (0, 4, 5, 1), (3, 2, 6, 7), (0, 3, 7, 4), (1, 5, 6, 2)):
+            if rs.rand() < 0.85:
+                s1, s2, s3 = _quad(c[a], c[b], c[cc], c[d])
+                add(np.stack([s1, s2, s3], axis=1), normals_mode="flat")
+    for _ in range(int(rs.randint(8, 60))):  # soup at mixed scales
+        scale = float(10 ** rs.uniform(-1.7, 0.9))
+        ctr = U(-4.0, 4.0, 3)
+        add((ctr + U(-scale, scale, 1, 3, 3)).astype(f32))
+    for _ in range(int(rs.randint(1, 4))):  # fans around one vertex
+        apex = U(-3.0, 3.0, 3)
+        rim = apex + U(-1.5, 1.5, int(rs.randint(4, 9)), 3)
+        add(np.stack([np.broadcast_to(apex, rim.shape), rim, np.roll(rim, 1, axis=0)], axis=1))
+    for _ in range(int(rs.randint(1, 4))):  # slivers
+        a = U(-4.0, 4.0, 3)
+        b = a + U(-3.0, 3.0, 3)
+        add(np.stack([a, b, (a + b) * f32(0.5) + U(-0.003, 0.003, 3)])[None])
+    for _ in range(int(rs.randint(1, 4))):  # coincident copies and coplanar stacks: exact distance ties, in one leaf or in several
+        t = (U(-3.0, 3.0, 3) + U(-1.2, 1.2, 3, 3)).astype(f32)
+        copies = int(rs.randint(2, 5))
+        for i in range(copies):
+            add(t[None] if rs.rand() < 0.6 else (t + (t[1] - t[0]) * f32(0.25 * i))[None])
+    for _ in range(int(rs.randint(1, 4))):  # axis-aligned sheets: bounding boxes of zero thickness
+        axis = int(rs.randint(0, 3))
+        q = U(-3.0, 3.0, 4, 3)
+        q[:, axis] = f32(rs.choice([0.0, 1.0, -2.5, float(U(-3, 3))]))
+        add(np.stack([q[[0, 0]], q[[1, 2]], q[[2, 3]]], axis=1))
+    for _ in range(int(rs.randint(0, 3))):  # smooth spheres
+        v, f = _icosphere(int(rs.randint(0, 3)))
+        r, ctr = float(U(0.3, 1.6)), U(-3.0, 3.0, 3)
+        add((v * r + ctr).astype(f32)[f], normals_mode="given", n=v.astype(f32)[f])
+    hostile = {"point", "pair", "collinear", "far", "tiny", "light"} if hostile is True else set(hostile or ())
+    if hostile:
+        p, q = U(-2.0, 2.0, 3), U(-2.0, 2.0, 3)
+        far, tiny = U(-1.0, 1.0, 1, 3, 3) * f32(1e6), U(-2.0, 2.0, 3) + U(-1e-6, 1e-6, 1, 3, 3)
+        if "point" in hostile:
+            add(np.stack([p, p, p])[None], normals_mode="flat")   # a point: N = 0/0
+        if "pair" in hostile:
+            add(np.stack([p, p, q])[None], normals_mode="zero")   # two equal vertices
+        if "collinear" in hostile:  # three distinct vertices on a line: passes the importer's ordering ASSERT, N = 0/0 all the same
+            a, e = np.round(p * 4) / 4, np.array([0.5, -0.25, 0.75], f32)
+            add(np.stack([a, a + e, a + 2 * e]).astype(f32)[None], normals_mode="flat")
+        if "far" in hostile:
+            add(far.astype(f32), normals_mode="flat")             # far, huge
+        if "tiny" in hostile:
+            add(tiny.astype(f32), normals_mode="tilted")
+    tris = _concat_tris(parts)
+
+    lights = []
+    for i in range(n_lights):
+        kind = rs.choice(["point", "spot", "directional"]) if n_lights > 1 or rs.rand() < 0.6 else "point"
+        col = tuple(U(0.2, 1.0, 3)) + (1.0,)
+        pos = U(-6.0, 6.0, 3) * f32(1.0 if rs.rand() < 0.8 else 20.0)
+        if "light" in hostile and i == 0:
+            pos = tris["S1"][0][:3].copy()  # exactly on a vertex
+        if kind == "point":
+            lights.append(light_point(pos, color=col, power=float(10 ** rs.uniform(-1, 3))))
+        elif kind == "spot":
+            lights.append(light_spot(pos, -pos + U(-2.0, 2.0, 3), cone_angle=float(U(0.2, 2.0)), penumbra_angle=float(U(0.0, 0.6)),
+                                     color=col, intensity=float(10 ** rs.uniform(-1, 2))))
+        else:
+            lights.append(light_directional(U(-1.0, 1.0, 3) + f32(1e-3), color=col, power=float(10 ** rs.uniform(-1.5, 0.7))))
+    eye = U(-7.0, 7.0, 3)
+    view = (U(-1.0, 1.0, 3) - eye).astype(f32)
+    view = view / np.linalg.norm(view)
+    right = np.cross(view, U(-1.0, 1.0, 3))
+    right = right / np.linalg.norm(right) * float(U(0.4, 1.4))
+    up = np.cross(right, view) * float(U(0.5, 1.5)) * height / width + U(-0.1, 0.1, 3)
+    pos, d, r, u = camera(eye, view, right, up)
+    return Scene(tris, _records(lights, S.Light), _records(mats, S.Material),
+                 np.array(textures, dtype=S.Texture) if textures else np.zeros(0, S.Texture), np.concatenate(texels), sky, pos, d, r, u,
+                 name=f"fuzz{seed}" + ("h" if hostile else "") + f"_l{n_lights}", meta={"seed": int(seed)})
+
+
 def build(name, width, height):
     """Named scenes used by tests, fixtures and the bench."""
     if name == "cornell":
@@ -547,6 +698,9 @@ def build(name, width, height):
         return material_mix(width, height)
     if name.startswith("feat_"):
         return feature_scene(name[5:], width, height)
+    m = re.fullmatch(r"fuzz(\d+)(h?)_l(\d+)", name)
+    if m:
+        return fuzz_scene(int(m.group(1)), width, height, n_lights=int(m.group(3)), hostile=bool(m.group(2)))
     if name.startswith("tris"):
         spec = name[4:]
         n = int(spec[:-1]) * {"k": 1000, "m": 1000000}[spec[-1]] if spec[-1] in "km" else int(spec)

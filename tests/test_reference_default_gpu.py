@@ -188,3 +188,75 @@ def test_random_sampler_vs_reference_default_build(scene_factory):
     assert (r_color[..., :3] <= color[..., :3] * (1 + 1e-5) + 1e-5).all()
     close = np.isclose(color, r_color, rtol=1e-5, atol=1e-5).all(-1)
     assert close[same].mean() > 0.75 and close.mean() > 0.6  # (measured: 0.85 and 0.76; the race decides)
+
+
+FUZZ_SPECIALISATIONS = ((1, "feat_64x64_d8", 64, 64, 8), (3, "matmix_96x96_d8", 96, 96, 8))  # lights, reference code object, W, H, depth
+
+
+@pytest.mark.parametrize("hostile", [False, True], ids=["importer", "hostile"])
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzzed_scenes_bit_exact_vs_both_reference_builds(seed, hostile):
+    """Scenes drawn from a seed (scenes.fuzz_scene: soup at mixed scales, fans, slivers, coincident and coplanar stacks, flat
+    boxes, tilted / zero normals, all material and light types at random, textures down to 1x1 with uv far outside [0, 1],
+    random cube maps, a skewed film frame; `hostile`: zero-area triangles, a light on a vertex, coordinates of 1e6): image
+    bits (NaNs included), sample counts and the three histograms equal the reference kernel's - its own build with
+    PTMI_FLAG_DEFAULT_ARITHMETIC, its strict build without - and the CPU oracle's in both arithmetics."""
+    import warnings
+    problems = []
+
+    def check(ours, ref, what):
+        try:
+            _assert_equal_to_reference(ours, ref, what)
+        except AssertionError as e:
+            problems.append(str(e).split("\n")[0])
+
+    for n_lights, case, w, h, d in FUZZ_SPECIALISATIONS:
+        if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
+            pytest.skip("oracle/_ref code objects not present")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (the hostile scenes divide 0 by 0 on purpose, as the importer would)
+            sc = bvh_create(scenes.build(f"fuzz{seed}{'h' if hostile else ''}_l{n_lights}", w, h))
+        spp = 24
+        for strict in (False, True):
+            flags = 0 if strict else DA
+            what = f"{sc.name} ({'strict' if strict else 'default'} build)"
+            ours = render_scene(sc, w, h, d, spp, flags=flags)
+            check(ours, O.ref_gpu_render(case, sc, w, h, d, spp, strict=strict), what)
+            check(render_scene(sc, w, h, d, spp, flags=flags | backend.FLAG_MEGAKERNEL), ours, what + ": one-path-per-lane kernel vs wavefront kernel")
+            o = O.oracle_render(sc, w, h, d, 3, default_arithmetic=not strict)
+            check(render_scene(sc, w, h, d, 3, flags=flags), o, what + ": integrator vs CPU oracle")
+    assert not problems, "\n".join(problems)
+
+
+def test_scenes_with_nan_distances_go_to_the_literal_kernel():
+    """A zero-area triangle (N = 0/0 as the importer computes it) is ACCEPTED by the reference for every ray that reaches it, with
+    a NaN distance; the context then serves the scene with the one-path-per-lane kernel - for ptmi_render and for
+    ptmi_render_snapshots alike - says why, and refuses SUPER_SAMPLING (wavefront kernel only) instead of rendering other pixels."""
+    import warnings
+    case, w, h, d = "feat_64x64_d8", 64, 64, 8
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tame, wild = bvh_create(scenes.build("fuzz3_l1", w, h)), bvh_create(scenes.build("fuzz3h_l1", w, h))
+    be = backend.Backend().setup_context(w, h, d, 1, S.JITTERED, flags=DA)
+    try:
+        be.initialize_memory(tame)
+        assert be.literal_kernel_reason() is None
+        be.initialize_memory(wild)
+        assert "triangle" in be.literal_kernel_reason()
+        be.render_snapshots(0, 6, 0)
+        images = [be.read_snapshot(k) for k in range(6)]
+        stats = be.read_statistics()
+        be.initialize_memory(tame)
+        assert be.literal_kernel_reason() is None
+    finally:
+        be.release()
+    color, count, ref_stats, _ = render_scene(wild, w, h, d, 6, flags=DA | backend.FLAG_MEGAKERNEL)
+    assert np.array_equal(images[5][0].view(np.uint32), color.view(np.uint32)) and np.array_equal(images[5][1], count)
+    assert all(np.array_equal(a, b) for a, b in zip(stats, ref_stats))
+    c3, n3, _, _ = render_scene(wild, w, h, d, 3, flags=DA | backend.FLAG_MEGAKERNEL)
+    assert np.array_equal(images[2][0].view(np.uint32), c3.view(np.uint32)) and np.array_equal(images[2][1], n3)
+    if O.have_ref_kernel(case):
+        r_color, r_count, _, _ = O.ref_gpu_render(case, wild, w, h, d, 6)
+        assert np.array_equal(r_color.view(np.uint32), color.view(np.uint32)) and np.array_equal(r_count, count)
+    with pytest.raises(backend.PtmiError, match="SUPER_SAMPLING"):
+        render_scene(wild, w, h, d, 2, flags=DA, super_sampling=True)
