@@ -545,9 +545,10 @@ def fuzz_scene(seed, width, height, n_lights=1, hostile=False):
     reference kernel beside the integrator (tests/test_reference_default_gpu.py): whatever the importer's conventions
     (``triangle_create`` ...) can produce, in proportions no hand-made scene has.
 
-    * 40-300 triangles at scales from 0.02 to 8 around the origin inside a (sometimes missing) box of six big quads:
-      free soup, fans sharing a vertex, slivers, stacks of coplanar and of exactly coincident triangles (distance ties),
-      axis-aligned sheets (flat bounding boxes), one or two smooth spheres;
+    * 40-300 triangles (every fourth seed: clusters of a few thousand) at scales from 0.02 to 8 around the origin inside a
+      (sometimes missing) box of six big quads: free soup, fans sharing a vertex, slivers, stacks of coplanar and of exactly
+      coincident triangles (distance ties; every fifth seed up to 40 of them: a leaf that cannot be split), axis-aligned
+      sheets (flat bounding boxes), one or two smooth spheres;
     * per-vertex normals: flat, smooth, zero (the importer's fallback to N with w = 1), or tilted far off the face;
     * 3-9 materials of all five types with colours from 0 to 1.2, opacities from 0 to 1, a third of them textured
       (odd sizes down to 1x1; uv from -3 to 4, so every wrap is taken), different materials on the two sides;
@@ -625,6 +626,14 @@ def fuzz_scene(seed, width, height, n_lights=1, hostile=False):
         scale = float(10 ** rs.uniform(-1.7, 0.9))
         ctr = U(-4.0, 4.0, 3)
         add((ctr + U(-scale, scale, 1, 3, 3)).astype(f32))
+    if seed % 4 == 3:  # every fourth scene: a few thousand small triangles in clusters (a tree 12-16 levels deep)
+        for _ in range(int(rs.randint(3, 9))):
+            k, ctr, spread = int(rs.randint(100, 700)), U(-3.5, 3.5, 3), float(10 ** rs.uniform(-0.8, 0.3))
+            c = ctr + rs.normal(0, spread, (k, 1, 3)).astype(f32)
+            add((c + U(-0.08, 0.08, k, 3, 3) * f32(spread * 2)).astype(f32), normals_mode=rs.choice(["flat", "tilted"]))
+    if seed % 5 == 2:  # a leaf the builder cannot split: many coincident triangles (more than a leaf's count field holds)
+        t = (U(-2.0, 2.0, 3) + U(-1.5, 1.5, 3, 3)).astype(f32)
+        add(np.repeat(t[None], int(rs.randint(9, 40)), axis=0))
     for _ in range(int(rs.randint(1, 4))):  # fans around one vertex
         apex = U(-3.0, 3.0, 3)
         rim = apex + U(-1.5, 1.5, int(rs.randint(4, 9)), 3)
@@ -678,8 +687,8 @@ def fuzz_scene(seed, width, height, n_lights=1, hostile=False):
                                      color=col, intensity=float(10 ** rs.uniform(-1, 2))))
         else:
             lights.append(light_directional(U(-1.0, 1.0, 3) + f32(1e-3), color=col, power=float(10 ** rs.uniform(-1.5, 0.7))))
-    eye = U(-7.0, 7.0, 3)
-    view = (U(-1.0, 1.0, 3) - eye).astype(f32)
+    eye = U(-7.0, 7.0, 3) * f32(rs.choice([1.0, 1.0, 0.3, 3.0]))  # (0.3: usually inside the clutter, 3: outside the room)
+    view = (U(-1.0, 1.0, 3) - eye).astype(f32) * f32(rs.choice([1.0, 1.0, 1.0, -1.0]))  # (-1: looking away, mostly sky)
     view = view / np.linalg.norm(view)
     right = np.cross(view, U(-1.0, 1.0, 3))
     right = right / np.linalg.norm(right) * float(U(0.4, 1.4))
@@ -690,6 +699,57 @@ def fuzz_scene(seed, width, height, n_lights=1, hostile=False):
                  name=f"fuzz{seed}" + ("h" if hostile else "") + f"_l{n_lights}", meta={"seed": int(seed)})
 
 
+def corrupt_records(scene, seed):
+    """What the arrays can hold although no importer writes it - the integrator takes raw records (the scene-cache files,
+    any host that fills GlobalVars itself), and whatever the reference makes of them is the contract: geometric normals that
+    are not unit length, flipped, or belong to another plane; vertices out of the importer's lexicographic order; w
+    components that are not 1 (all three equal, or each its own: the triangle test's generic form); vertex normals of any
+    length; material and light types outside their enums, opacities outside [0, 1], negative powers; a spot light whose
+    inner cone is the narrower one.  In place, before the tree is built; returns the scene."""
+    rs = np.random.RandomState(77003 * int(seed) + 5)
+    t = scene.triangulation
+    n = len(t)
+    pickn = lambda frac: np.flatnonzero(rs.rand(n) < frac)
+    for i in pickn(0.25):
+        t["N"][i][:3] *= np.float32(rs.choice([-1.0, 0.3, 2.5, 1.0 + 1e-3]))
+    for i in pickn(0.05):
+        t["N"][i][:3] = (t["N"][i][:3] + rs.uniform(-0.5, 0.5, 3)).astype(f32)
+    for i in pickn(0.1):
+        a, b = rs.choice(3, 2, replace=False)
+        for grp in (("S1", "S2", "S3"), ("N1", "N2", "N3"), ("UVP1", "UVP2", "UVP3"), ("UVN1", "UVN2", "UVN3")):
+            x, y = t[grp[a]][i].copy(), t[grp[b]][i].copy()
+            t[grp[a]][i], t[grp[b]][i] = y, x
+    mode = rs.choice(["importer", "equal", "own"])
+    if mode != "importer":
+        for i in pickn(0.5 if mode == "equal" else 0.2):
+            w3 = rs.uniform(-2, 3, 3).astype(f32) if mode == "own" else np.repeat(f32(rs.uniform(-2, 3)), 3)
+            for k, name in enumerate(("S1", "S2", "S3")):
+                t[name][i][3] = w3[k]
+    for i in pickn(0.1):
+        for name in ("N1", "N2", "N3"):
+            t[name][i] = (t[name][i] * np.float32(rs.choice([0.0, 0.5, 3.0, -1.0]))).astype(f32)
+    m = scene.materiaux
+    for i in range(len(m)):
+        r = rs.rand()
+        if r < 0.15:
+            m["type"][i] = int(rs.choice([5, 7, 255]))
+        elif r < 0.3:
+            m["opacity"][i] = np.float32(rs.choice([-0.5, 1.5, 0.0]))
+    li = scene.lights
+    for i in range(len(li)):
+        r = rs.rand()
+        if r < 0.2 and len(li) > 1:
+            li["type"][i] = int(rs.choice([3, 9]))
+        elif r < 0.35:
+            li["power"][i] = -li["power"][i]
+        elif r < 0.5:
+            li["cosOfInnerFallOffAngle"][i], li["cosOfOuterFallOffAngle"][i] = li["cosOfOuterFallOffAngle"][i], li["cosOfInnerFallOffAngle"][i]
+        if rs.rand() < 0.3:
+            li["direction"][i][:3] *= np.float32(rs.choice([0.0, 2.0]))  # (a direction that is not a unit vector)
+    scene.name += "r"
+    return scene
+
+
 def build(name, width, height):
     """Named scenes used by tests, fixtures and the bench."""
     if name == "cornell":
@@ -698,9 +758,10 @@ def build(name, width, height):
         return material_mix(width, height)
     if name.startswith("feat_"):
         return feature_scene(name[5:], width, height)
-    m = re.fullmatch(r"fuzz(\d+)(h?)_l(\d+)", name)
+    m = re.fullmatch(r"fuzz(\d+)(h?)(r?)_l(\d+)", name)
     if m:
-        return fuzz_scene(int(m.group(1)), width, height, n_lights=int(m.group(3)), hostile=bool(m.group(2)))
+        sc = fuzz_scene(int(m.group(1)), width, height, n_lights=int(m.group(4)), hostile=bool(m.group(2)))
+        return corrupt_records(sc, int(m.group(1))) if m.group(3) else sc
     if name.startswith("tris"):
         spec = name[4:]
         n = int(spec[:-1]) * {"k": 1000, "m": 1000000}[spec[-1]] if spec[-1] in "km" else int(spec)

@@ -260,3 +260,67 @@ def test_scenes_with_nan_distances_go_to_the_literal_kernel():
         assert np.array_equal(r_color.view(np.uint32), color.view(np.uint32)) and np.array_equal(r_count, count)
     with pytest.raises(backend.PtmiError, match="SUPER_SAMPLING"):
         render_scene(wild, w, h, d, 2, flags=DA, super_sampling=True)
+
+
+# (reference code object, lights, sampler, W, H, depth, SUPER_SAMPLING)
+FUZZ_OTHER_SPECIALISATIONS = [("cornell_64x48_d4_uni", 1, S.UNIFORM, 64, 48, 4, False), ("matmix_96x96_d8_uni", 3, S.UNIFORM, 96, 96, 8, False),
+                              ("tris20k_96x64_d6", 1, S.JITTERED, 96, 64, 6, False), ("cornell_64x48_d4_ss", 1, S.JITTERED, 64, 48, 4, True),
+                              ("cornell_128x128_d8", 1, S.JITTERED, 128, 128, 8, False), ("cornell_64x48_d2", 1, S.JITTERED, 64, 48, 2, False),
+                              ("tris1m_160x90_d10", 1, S.JITTERED, 160, 90, 10, False), ("cornell_64x48_d1", 1, S.JITTERED, 64, 48, 1, False)]
+
+
+@pytest.mark.parametrize("seed", range(10, 34))
+def test_fuzzed_scenes_other_samplers_sizes_and_depths(seed):
+    """More seeds, each through another specialisation of the reference kernel: the UNIFORM sampler, SUPER_SAMPLING (the adaptive
+    stop decisions must fall on the same samples), ray depths 1 to 10, image sizes that are no multiple of a tile; odd seeds
+    carry the hostile records (not with SUPER_SAMPLING, which such a scene refuses)."""
+    import warnings
+    case, n_lights, sampler, w, h, d, ss = FUZZ_OTHER_SPECIALISATIONS[seed % len(FUZZ_OTHER_SPECIALISATIONS)]
+    hostile = seed % 2 == 1 and not ss
+    if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
+        pytest.skip("oracle/_ref code objects not present")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc = bvh_create(scenes.build(f"fuzz{seed}{'h' if hostile else ''}_l{n_lights}", w, h))
+    spp = 20
+    problems = []
+    for strict in (False, True):
+        flags = 0 if strict else DA
+        what = f"{sc.name} through {case} ({'strict' if strict else 'default'} build)"
+        ours = render_scene(sc, w, h, d, spp, sampler=sampler, flags=flags, super_sampling=ss)
+        for other, label in ((O.ref_gpu_render(case, sc, w, h, d, spp, strict=strict), what),
+                             (O.oracle_render(sc, w, h, d, spp, sampler=sampler, super_sampling=ss, default_arithmetic=not strict), what + ": integrator vs CPU oracle")):
+            try:
+                _assert_equal_to_reference(ours, other, label)
+            except AssertionError as e:
+                problems.append(str(e).split("\n")[0])
+    assert not problems, "\n".join(problems)
+
+
+@pytest.mark.parametrize("seed", range(40, 56))
+def test_fuzzed_scenes_with_records_no_importer_writes(seed):
+    """scenes.corrupt_records on top of a fuzzed scene: geometric normals of any length and side, vertices out of order, w
+    components that are not 1 (the generic triangle test when they differ inside a triangle), material and light types outside
+    their enums, opacities outside [0, 1], negative powers, inverted cones - the raw arrays are the interface, and the
+    reference's handling of them is the contract.  Odd seeds add the hostile records."""
+    import warnings
+    problems = []
+    for n_lights, case, w, h, d in FUZZ_SPECIALISATIONS:
+        if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
+            pytest.skip("oracle/_ref code objects not present")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sc = bvh_create(scenes.build(f"fuzz{seed}{'h' if seed % 2 else ''}r_l{n_lights}", w, h))
+        spp = 16
+        for strict in (False, True):
+            flags = 0 if strict else DA
+            what = f"{sc.name} ({'strict' if strict else 'default'} build)"
+            ours = render_scene(sc, w, h, d, spp, flags=flags)
+            for other, label in ((O.ref_gpu_render(case, sc, w, h, d, spp, strict=strict), what),
+                                 (render_scene(sc, w, h, d, spp, flags=flags | backend.FLAG_MEGAKERNEL), what + ": one-path-per-lane kernel vs wavefront kernel"),
+                                 (O.oracle_render(sc, w, h, d, spp, default_arithmetic=not strict), what + ": integrator vs CPU oracle")):
+                try:
+                    _assert_equal_to_reference(ours, other, label)
+                except AssertionError as e:
+                    problems.append(str(e).split("\n")[0])
+    assert not problems, "\n".join(problems)
