@@ -19,6 +19,12 @@ FIXTURE_RANGES = [(0, 8), (8, 8)]  # (first iteration, count): two shards of a 1
 STRICT_SPP = 4                      # iterations 0..3 of the reference's strict build are stored in full (bit-exact pin)
 FEATURE_CASE = ("feat_64x64_d8", 64, 64, 8)  # one specialisation of the reference kernel for every scenes.feature_scene
 FEATURE_SPP = 8
+# scenes.fuzz_scene / corrupt_records scenes whose reference results (both builds) are committed as digests
+# (tests/golden/ref_fuzz.npz): h = hostile records (NaN distances), r = records no importer writes, _l<n> = lights.
+# 1 light -> code object feat_64x64_d8, 3 lights -> matmix_96x96_d8
+FUZZ_FIXTURES = ["fuzz0_l1", "fuzz0h_l1", "fuzz1_l3", "fuzz1h_l3", "fuzz2_l1", "fuzz3_l1", "fuzz5h_l1", "fuzz7h_l3", "fuzz40r_l1", "fuzz41hr_l1",
+                 "fuzz42r_l3", "fuzz43hr_l3", "fuzz46r_l1", "fuzz47hr_l3"]
+FUZZ_CASE = {1: ("feat_64x64_d8", 64, 64, 8), 3: ("matmix_96x96_d8", 96, 96, 8)}
 
 
 def result_digest(color, count, depths, bbx, tri):

@@ -33,8 +33,39 @@ def scene_digest(sc):
     return h.hexdigest()
 
 
-def main(out_dir, features_only=False):
+def full_scene_digest(sc):
+    """Every byte the kernel can read (the fuzzed scenes vary all of it)."""
+    h = hashlib.sha256(scene_digest(sc).encode())
+    for a in (sc.triangulation, sc.lights, sc.materiaux, sc.textures, sc.texturesData, sc.sky, sc.cameraPosition, sc.cameraDirection,
+              sc.cameraRight, sc.cameraUp):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def fuzz_fixtures(out_dir):
+    """Digests of the reference's results (both builds, 8 spp) on the seeded scenes of cases.FUZZ_FIXTURES."""
+    import warnings
+    digests = {}
+    for name in cases.FUZZ_FIXTURES:
+        case, w, h, d = cases.FUZZ_CASE[int(name.rsplit("_l", 1)[1])]
+        if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
+            print("skip", name, "(no code object)")
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sc = bvh_create(scenes.build(name, w, h))
+        digests[name + "_scene"] = full_scene_digest(sc)
+        for strict, key in ((True, name), (False, name + "_default")):
+            color, count, (dep, bbx, tri), _ = O.ref_gpu_render(case, sc, w, h, d, cases.FEATURE_SPP, strict=strict)
+            digests[key] = cases.result_digest(color, count, dep, bbx, tri)
+        print("fuzz", name, digests[name][:16], digests[name + "_default"][:16], flush=True)
+    np.savez_compressed(os.path.join(out_dir, "ref_fuzz.npz"), **{k: np.array(v) for k, v in digests.items()})
+
+
+def main(out_dir, features_only=False, fuzz_only=False):
     os.makedirs(out_dir, exist_ok=True)
+    if fuzz_only:
+        return fuzz_fixtures(out_dir)
     for case, (name, sampler, w, h, d) in ({} if features_only else cases.CASES).items():
         if not O.have_ref_kernel(case):
             print("skip", case, "(no code object)")
@@ -85,8 +116,10 @@ def main(out_dir, features_only=False):
             digests[feature + "_default"] = cases.result_digest(color, count, dep, bbx, tri)
             print("feature", feature, digests[feature][:16], digests[feature + "_default"][:16], flush=True)
         np.savez_compressed(os.path.join(out_dir, f"ref_{fcase}_features.npz"), **{k: np.array(v) for k, v in digests.items()})
+    fuzz_fixtures(out_dir)
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    main(args[0] if args else os.path.join(ROOT, "gpurun_out", "golden"), features_only="--features-only" in sys.argv)
+    main(args[0] if args else os.path.join(ROOT, "gpurun_out", "golden"), features_only="--features-only" in sys.argv,
+         fuzz_only="--fuzz-only" in sys.argv)

@@ -159,3 +159,28 @@ def test_oracle_equals_the_reference_strict_build_feature_by_feature(built):
         assert str(fx[feature + "_scene"]) == mk.scene_digest(sc), "scene generator changed since the fixture was made"
         color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.FEATURE_SPP)
         assert cases.result_digest(color, count, dep, bbx, tri) == str(fx[feature]), feature
+
+
+def test_oracle_equals_both_reference_builds_on_fuzzed_scenes(built):
+    """Seeded scenes nobody arranged (scenes.fuzz_scene / corrupt_records: soup, ties, unsplittable leaves, all material and
+    light types, records no importer writes, zero-area triangles whose NaN distances the reference accepts): the oracle in
+    either arithmetic equals the digest of that build of the reference (tests/golden/ref_fuzz.npz, made on the MI355X)."""
+    import importlib.util
+    import warnings
+    from opencl_pathtracer_amd import scenes, bvh_create
+    path = os.path.join(GOLDEN, "ref_fuzz.npz")
+    if not os.path.exists(path):
+        pytest.skip("fuzz fixture not generated yet")
+    fx = np.load(path)
+    spec = importlib.util.spec_from_file_location("mkfx", os.path.join(GOLDEN, "make_reference_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for name in cases.FUZZ_FIXTURES:
+        _, w, h, d = cases.FUZZ_CASE[int(name.rsplit("_l", 1)[1])]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sc = bvh_create(scenes.build(name, w, h))
+        assert str(fx[name + "_scene"]) == mk.full_scene_digest(sc), f"{name}: scene generator changed since the fixture was made"
+        for da, key in ((False, name), (True, name + "_default")):
+            color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.FEATURE_SPP, default_arithmetic=da)
+            assert cases.result_digest(color, count, dep, bbx, tri) == str(fx[key]), key
