@@ -576,3 +576,52 @@ def _record_north_star(case, spp, rms, floor):
     data[case] = {"spp": spp, "rms_default_arithmetic_mode_vs_reference_default_build": [float(x) for x in rms],
                   "rms_strict_mode_vs_reference_default_build": None if floor is None else [float(x) for x in floor]}
     json.dump(data, open(path, "w"), indent=1)
+
+
+@pytest.mark.parametrize("seed", [3, 6, 12, 21, 41, 43])
+def test_fuzzed_scenes_in_every_other_mode_vs_oracle(seed):
+    """The seeded scenes of scenes.fuzz_scene (odd seeds with the hostile records, seeds from 40 with corrupted ones) through
+    what the reference-kernel fuzz tests do not reach: the RANDOM sampler, Russian roulette, the source-seed rule, the
+    statistics build of the wavefront kernel (same image, no item-protocol violation - or, for a scene served by the
+    one-path-per-lane kernel, no statistics), and two listed devices.  Bit-exact against the oracle in both arithmetics."""
+    import warnings
+    from opencl_pathtracer_amd import scenes, bvh_create
+    w, h, d = 72, 40, 7
+    name = f"fuzz{seed}{'h' if seed % 2 else ''}{'r' if seed >= 40 else ''}_l{1 + 2 * (seed % 3 == 0)}"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc = bvh_create(scenes.build(name, w, h))
+    DA = backend_flags.FLAG_DEFAULT_ARITHMETIC
+    for da in (False, True):
+        f = DA if da else 0
+        base = render_scene(sc, w, h, d, 5, flags=f)
+        o = O.oracle_render(sc, w, h, d, 5, default_arithmetic=da)
+        assert np.array_equal(base[0].view(np.uint32), o[0].view(np.uint32)) and np.array_equal(base[1], o[1]) and base[3] == o[3]
+        assert all(np.array_equal(a, b) for a, b in zip(base[2], o[2]))
+        # RANDOM sampler: atomic float sums, so equal counts and close colours (NaN where the oracle has NaN)
+        color, count, (dep, _, _), counters = render_scene(sc, w, h, d, 5, sampler=S.RANDOM, flags=f)
+        o_color, o_count, (o_dep, _, _), totals = O.oracle_render(sc, w, h, d, 5, sampler=S.RANDOM, default_arithmetic=da)
+        assert np.array_equal(count, o_count) and counters == totals and np.array_equal(dep, o_dep)
+        assert np.allclose(color, o_color, rtol=1e-4, atol=1e-5, equal_nan=True)
+        # Russian roulette and the source-seed rule (non-parity modes)
+        rr = render_scene(sc, w, h, d, 5, flags=f | backend_flags.FLAG_RUSSIAN_ROULETTE | backend_flags.FLAG_SOURCE_SEED)
+        o_rr = O.oracle_render(sc, w, h, d, 5, russian_roulette=True, source_seed=True, default_arithmetic=da)
+        assert np.array_equal(rr[0].view(np.uint32), o_rr[0].view(np.uint32)) and rr[3] == o_rr[3]
+        # the statistics build
+        be = Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, flags=f | backend_flags.FLAG_SCHEDULER_STATS)
+        try:
+            be.initialize_memory(sc)
+            literal = be.literal_kernel_reason() is not None
+            be.render(0, 5)
+            color, count = be.read_image()
+            st = be.scheduler_stats()
+        finally:
+            be.release()
+        assert literal == (seed % 2 == 1)
+        assert np.array_equal(color.view(np.uint32), base[0].view(np.uint32)) and np.array_equal(count, base[1])
+        assert st["leaf_item_violations"] == 0 and (st["trips_node"] > 0) == (not literal)
+        # one GPU listed twice: sample counts, counters and histograms of the single context; the image up to the association
+        # of the two partial sums (NaN pixels of a hostile scene stay NaN)
+        two = render_scene(sc, w, h, d, 5, flags=f, devices=[0, 0])
+        assert np.array_equal(two[1], base[1]) and two[3] == base[3] and all(np.array_equal(a, b) for a, b in zip(two[2], base[2]))
+        assert np.allclose(two[0], base[0], rtol=2e-6, atol=1e-6, equal_nan=True)
