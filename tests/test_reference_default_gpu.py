@@ -324,3 +324,19 @@ def test_fuzzed_scenes_with_records_no_importer_writes(seed):
                 except AssertionError as e:
                     problems.append(str(e).split("\n")[0])
     assert not problems, "\n".join(problems)
+
+
+@pytest.mark.parametrize("name", ["fuzz3_l1", "fuzz47r_l1", "fuzz7h_l1"])
+def test_fuzzed_scenes_at_full_size_vs_reference_default_build(name):
+    """1920 x 1080, depth 10 (the code object of BASELINE configs[2]: the reference bakes in sizes, depth and light count, not
+    the scene): thousands of triangles in clusters with every material type and textures - the GENERAL shading specialisation
+    of the wavefront kernel at full size, which the two BASELINE scenes (plain ones) do not reach -, the same with corrupted
+    records, and a hostile one through the one-path-per-lane kernel.  All 2 M pixels, counts and histograms equal."""
+    import warnings
+    case, w, h, d, spp = "tris1m_1920x1080_d10", 1920, 1080, 10, 2
+    if not O.have_ref_kernel(case):
+        pytest.skip("oracle/_ref code object not present")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc = bvh_create(scenes.build(name, w, h))
+    _assert_equal_to_reference(render_scene(sc, w, h, d, spp, flags=DA), O.ref_gpu_render(case, sc, w, h, d, spp), name)
