@@ -233,13 +233,14 @@ void ptmi_release(ptmi_ctx* ctx);
 int ptmi_get_counters(ptmi_ctx* ctx, ptmi_counters* out);
 int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out);
 int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out);
-/* NULL while the uploaded scene is rendered by the kernel the context asked for.  Otherwise why it is rendered by the
- * one-path-per-lane kernel (as with PTMI_FLAG_MEGAKERNEL: same results, slower): the scene holds records on which the
- * reference's triangle test (FullKernel.cl:519-589) produces NaN distances - zero-area triangles, whose normal the importer
- * computes as 0/0, non-finite or astronomically large coordinates.  The reference ACCEPTS such a triangle for every ray that
- * reaches it (all its rejections are comparisons) and from then on takes the LAST triangle that passes, not the nearest; only
- * the literal loop order reproduces that bit for bit.  With super_sampling such a scene is PTMI_ERR_UNSUPPORTED.
- * The string lives until the next ptmi_initialize_memory / ptmi_release. */
+/* NaN distances.  The reference's triangle test (FullKernel.cl:519-589) rejects with comparisons only, so a triangle on which
+ * it computes NaNs is ACCEPTED, with a NaN distance, and from then on the LAST triangle that passes wins, not the nearest.
+ * The integrator reproduces that bit for bit.  Where the RAY is not a number (a refraction at |cos| = 1 + 1 ulp, cl:235) the
+ * wavefront kernel gives the path up and re-traces it with the reference's literal loops (JITTERED / UNIFORM samplers).
+ * Where the scene's RECORDS are the source - zero-area triangles, whose normal the importer computes as 0/0; non-finite or
+ * astronomically large coordinates - the whole scene is rendered by the one-path-per-lane kernel (as with
+ * PTMI_FLAG_MEGAKERNEL: same results, slower; PTMI_ERR_UNSUPPORTED with super_sampling): this call then returns why, else
+ * NULL.  The string lives until the next ptmi_initialize_memory / ptmi_release. */
 const char* ptmi_literal_kernel_reason(const ptmi_ctx* ctx);
 
 /* Device time of the integrator kernel launches issued by ptmi_render since the

@@ -47,6 +47,7 @@
 
 #include "ptmi_device.hpp"
 #include "ptmi_shading.hpp"
+#include "ptmi_literal_path.hpp"
 
 #include <cstring>
 
@@ -148,6 +149,10 @@ struct DWarm {
 // A finished path's three histogram bins in one word: depth (6 bits, < kStatDepthBins), box tests and triangle tests
 // (13 bits each; anything >= MAX_INTERSECTION_NUMBER = 5000 is not counted by the reference, stored as 8191).
 constexpr uint32_t kStatDepthBins = 64;
+// A path the wavefront kernel gives up (where it sets up a ray that is not a number, below): its radiance becomes this NaN - the
+// payload survives the additions and fused multiply-adds that follow (tools/microbench/nan_payload.hip) -, its counters
+// restart at zero, the launch's job-counter block gets a non-zero word 1, and redo_poisoned_kernel traces the path again.
+constexpr uint32_t kPoisonMarker = 0x7FC0DEADu;
 __device__ __forceinline__ uint32_t pack_path_statistics(uint32_t depth, uint32_t bbx, uint32_t tri)
 {
     static_assert(PTMI_MAX_INTERSECTION_NUMBER <= 8191, "13-bit fields");
@@ -847,7 +852,28 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
             if (new_ray) {
                 ray_set_direction(r, new_direction);
                 dir_signs = (r.d.x > 0 ? 1u : 0u) | (r.d.y > 0 ? 2u : 0u) | (r.d.z > 0 ? 4u : 0u);
+                // A ray that is not a number - a refraction at |cos| = 1 + 1 ulp takes the square root of a negative (cl:235),
+                // a hit on a fake plane 1e30 away overflows - makes every triangle test compute a NaN distance, and the
+                // reference ACCEPTS those (its rejections are comparisons, cl:533-567): from then on nothing is "too far" and
+                // the LAST triangle that passes wins - not a minimum over ordered keys, which is what a leaf pass keeps.
+                // With finite rays from origins below 2^40 and the records the upload admits (ptmi_api.cpp:
+                // scene_needs_literal_kernel) a distance is always a number.  So such a path is GIVEN UP here: it restarts
+                // its counters, takes a marked NaN for its radiance and its query ends before it starts - as a miss, so the
+                // next pass finishes the path the ordinary way (one segment, no hit) - and redo_poisoned_kernel, behind the
+                // launch, traces it again with the reference's literal loops.  (Not with the RANDOM sampler: nothing staged.)
+                const float o_size = __builtin_fabsf(r.o.x) + __builtin_fabsf(r.o.y) + __builtin_fabsf(r.o.z) + __builtin_fabsf(r.o.w);
+                const float d_size = __builtin_fabsf(r.d.x) + __builtin_fabsf(r.d.y) + __builtin_fabsf(r.d.z) + __builtin_fabsf(r.d.w);
+                const bool bad = owns_pixel && !((o_size <= 0x1p+40f) & (d_size <= 4.0f));  // (false for a NaN)
+                if (__builtin_expect(bad, 0)) {
+                    const float m = __uint_as_float(kPoisonMarker);
+                    radiance = v4(m, m, m, m);
+                    transfer = v4(1, 1, 1, 1);
+                    reflection = 0; p_bbx = 0; p_tri = 0;
+                    shadow = false;
+                    job_counter[1] = 1u;  // (the block is zeroed before every launch)
+                }
                 start_query();
+                if (__builtin_expect(bad, 0)) { cur = REF_NONE; tri_i = tri_end = 0; }
             }
             if (need_path) cur = alive ? REF_IDLE : REF_DEAD;
         }
@@ -872,6 +898,52 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
     if (tid == 0) block_counters[C_SHADOW] = block_counters[C_HITS] * sc.n_lights;
     __syncthreads();
     if (tid < C_COUNT) atomicAdd(&cold_scene().counters[tid], block_counters[tid]);
+}
+
+// The paths a wavefront launch gave up (marked radiance in the staging slot, counted as one segment without a hit), traced
+// again by the reference's loops as they are written (ptmi_literal_path.hpp): radiance, statistics word and totals as if the
+// launch had traced them.  Runs behind every staged wavefront launch on its stream and returns at once unless the launch
+// left a non-zero word 1 in its job-counter block.
+template <bool PRE>
+__global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, const uint32_t first_iteration, const uint32_t n_iterations,
+                                                               const uint32_t iteration_stride, float* __restrict__ stage,
+                                                               uint32_t* __restrict__ stage_stats, const uint32_t* __restrict__ job_counter)
+{
+    if (__builtin_nontemporal_load(&job_counter[1]) == 0u) return;  // (the same for every lane of the grid)
+    __shared__ uint32_t stack_mem[kStackDepth * kBlock];
+    __shared__ unsigned long long block_counters[C_TRI + 1];  // (two's complement: the one segment the launch counted is taken back)
+    const uint32_t tid = threadIdx.x;
+    if (tid <= C_TRI) block_counters[tid] = 0;
+    __syncthreads();
+    const uint32_t n_pixels = sc.width * sc.height, n_slots = n_pixels * n_iterations;
+    for (uint32_t slot = blockIdx.x * kBlock + tid; slot < n_slots; slot += gridDim.x * kBlock) {
+        const uint4 v = reinterpret_cast<const uint4*>(stage)[slot];
+        if (v.x != kPoisonMarker || v.y != kPoisonMarker || v.z != kPoisonMarker || v.w != kPoisonMarker) continue;
+        const uint32_t it_local = slot / n_pixels, pixel = slot - it_local * n_pixels;
+        const uint32_t gy = pixel / sc.width, gx = pixel - gy * sc.width;
+        const uint32_t it = first_iteration + it_local * iteration_stride;
+        float sx, sy;
+        uint32_t depth = 0, n_seg = 0, n_shadow = 0;
+        PathCounters pc;
+        const V4 radiance = trace_path<PRE>(sc, gx, gy, it, &stack_mem[tid], sx, sy, depth, n_seg, n_shadow, pc, sc.super_sampling != 0 && it > 5u);
+        reinterpret_cast<float4*>(stage)[slot] = make_float4(radiance.x, radiance.y, radiance.z, radiance.w);
+        if (stage_stats != nullptr) {
+            stage_stats[slot] = pack_path_statistics(depth, pc.bbx, pc.tri);
+        } else if (sc.hist_depths) {  // FullKernel.cl:1319-1331; the launch counted the path in the three zero bins
+            atomicSub(&sc.hist_depths[0], 1u); atomicSub(&sc.hist_bbx[0], 1u); atomicSub(&sc.hist_tri[0], 1u);
+            atomicAdd(&sc.hist_depths[depth], 1u);
+            if (pc.bbx < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_bbx[pc.bbx], 1u);
+            if (pc.tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[pc.tri], 1u);
+        }
+        // (the launch counted: one path, one segment, no hit)
+        atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)n_seg - 1ull);
+        atomicAdd(&block_counters[C_HITS], (unsigned long long)depth);
+        atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
+        atomicAdd(&block_counters[C_BBX], (unsigned long long)pc.bbx);
+        atomicAdd(&block_counters[C_TRI], (unsigned long long)pc.tri);
+    }
+    __syncthreads();
+    if (tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
 }
 
 // Histograms of the paths of one launch from their staged statistics words (FullKernel.cl:1319-1331: depth bin
@@ -1088,6 +1160,16 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
 #undef PTMI_LAUNCH_WF
 #undef PTMI_LAUNCH_WF_IMPL
         e = hipGetLastError();
+        if (e == hipSuccess && stage != nullptr) {
+            // behind the launch, on its stream: the paths it gave up, if any (returns at once otherwise)
+            if (sc.tris_precomputed)
+                hipLaunchKernelGGL(PTMI_DEV_NS::redo_poisoned_kernel<true>, dim3(1024), dim3(PTMI_DEV_NS::kBlock), 0, st, sc, first_iteration,
+                                   n_iterations, iteration_stride, stage, stage_stats, job_counter);
+            else
+                hipLaunchKernelGGL(PTMI_DEV_NS::redo_poisoned_kernel<false>, dim3(1024), dim3(PTMI_DEV_NS::kBlock), 0, st, sc, first_iteration,
+                                   n_iterations, iteration_stride, stage, stage_stats, job_counter);
+            e = hipGetLastError();
+        }
     }
     if (e != hipSuccess) {
         if (err) *err = std::string("render_wavefront_kernel launch: ") + hipGetErrorString(e);

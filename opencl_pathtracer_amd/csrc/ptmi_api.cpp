@@ -238,19 +238,25 @@ bool texture_ok(const ptmi_texture& t, uint32_t data_size)
     return end <= data_size;
 }
 
-// Can a NaN reach a query's limit in this scene?  The reference's triangle test rejects with comparisons only
-// (FullKernel.cl:533-567), so a triangle whose test produces NaNs - a zero-area triangle as the importer emits it: N =
+// Can the RECORDS of this scene make a triangle test compute a NaN distance?  The reference's test rejects with comparisons
+// only (FullKernel.cl:533-567), so a triangle on which it computes NaNs - a zero-area triangle as the importer emits it: N =
 // normalize(0) = 0/0 (Utils.h:144) - is ACCEPTED by every ray that reaches it, with a NaN squared distance: from then on
 // nothing is "too far" (:543, :92) and the LAST triangle that passes the remaining tests wins, whatever its distance.  The
 // one-path-per-lane kernel runs the reference's loops literally and reproduces this bit for bit.  The wavefront kernel's leaf
-// passes test the triangles of a leaf side by side and keep the minimum of (distance, order) keys - the same result as the
-// sequential loop only while distances are ordered, i.e. not NaN.  So a scene in which a NaN distance CAN occur is rendered
-// by the one-path-per-lane kernel (tests/test_reference_default_gpu.py::test_fuzzed_scenes...).  It cannot occur when
+// passes keep the minimum of (distance, order) keys - the sequential loop's result only while distances are ordered, i.e.
+// numbers.  Two sources of NaN distances, two remedies:
+//   * the RAY is not a number (a refraction at |cos| = 1 + 1 ulp, cl:235; an origin that overflowed): the wavefront kernel
+//     checks every ray it sets up, gives such a path up and the literal loops trace it again into its staging slot
+//     (kernel_wavefront.hip: redo_poisoned_kernel) - costs nothing in the traversal loop;
+//   * the RECORDS are: then the whole scene is rendered by the one-path-per-lane kernel (a test per accepted triangle in
+//     the leaf pass would find them, and costs 0.9 % on every scene: measured, not kept).  This function finds those scenes.
+// With finite rays from origins below 2^40 a distance is a number when
 //   * every triangle's vertices, normals and vertex normals, the lights' positions and directions and the camera are finite
-//     and at most 2^21 (normals: 16) in magnitude: then no product of the test overflows (ray parameter <= 2^48, barycentric
-//     numerators <= 2^119) and inf - inf / 0 * inf never forms, and
-//   * the barycentric determinant uv^2 - uu.vv of every triangle is non-zero with a finite reciprocal, in both arithmetics:
-//     then s and t are numbers, an accepted hit lies inside its triangle, and the next ray starts within the same bounds.
+//     and at most 2^21 (normals: 16) in magnitude: then the plane terms are finite, the ray parameter is (|N.d| >= 1e-5 or
+//     the triangle is rejected, cl:533), and so are the hit point and its distance (an overflow gives +inf: ordered), and
+//   * the barycentric determinant uv^2 - uu.vv of every triangle is non-zero with a finite reciprocal, in both arithmetics
+//     (s and t may still overflow for a hit on a corrupted record's plane far outside its triangle; they only gate the
+//     acceptance, they do not enter the order).
 // Returns the reason, or an empty string.
 std::string scene_needs_literal_kernel(const ptmi_scene* sc)
 {

@@ -750,6 +750,42 @@ def corrupt_records(scene, seed):
     return scene
 
 
+def corrupt_tree(scene, seed):
+    """The tree is the caller's too (the reference builds it on the host; the integrator takes it as an array): boxes that
+    do not bound what is below them (shrunk, grown), inverted on an axis (pMin > pMax), with a NaN or an infinite face,
+    marked empty; split axes that are not the builder's; leaves that hold fewer triangles than the builder gave them, or
+    none.  Structure (child indices, leaf ranges inside the triangle array) stays valid - the integrator refuses a tree that
+    would make it read out of bounds, which the reference would simply do.  In place, after the tree is built."""
+    rs = np.random.RandomState(990001 * int(seed) + 3)
+    b = scene.bvh
+    box = b["trianglesAABB"]
+    for i in range(1, len(b)):
+        r = rs.rand()
+        if r < 0.15:
+            c = (box["pMin"][i] + box["pMax"][i]) * f32(0.5)
+            k = rs.choice([0.3, 0.8, 1.5], 4).astype(f32)
+            half = (box["pMax"][i] - box["pMin"][i]) * f32(0.5) * k
+            box["pMin"][i], box["pMax"][i] = c - half, c + half
+        elif r < 0.18:
+            a = int(rs.randint(0, 3))
+            box["pMin"][i][a], box["pMax"][i][a] = box["pMax"][i][a], box["pMin"][i][a]
+        elif r < 0.20:
+            box[rs.choice(["pMin", "pMax"])][i][int(rs.randint(0, 3))] = np.nan
+        elif r < 0.22:
+            box["pMax"][i][int(rs.randint(0, 3))] = np.inf
+        elif r < 0.23:
+            box["pMin"][i][int(rs.randint(0, 3))] = -np.inf
+        elif r < 0.26:
+            box["isEmpty"][i] = 1
+        if b["isLeaf"][i]:
+            if rs.rand() < 0.05 and b["nbTriangles"][i] > 0:
+                b["nbTriangles"][i] -= 1
+        elif rs.rand() < 0.1:
+            b["cutAxis"][i] = int(rs.randint(0, 3))
+    scene.name += "t"
+    return scene
+
+
 def build(name, width, height):
     """Named scenes used by tests, fixtures and the bench."""
     if name == "cornell":

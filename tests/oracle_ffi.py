@@ -185,8 +185,8 @@ def oracle_render(scene, width, height, ray_max_depth, n_iterations, first_itera
     return color, count, (depths, bbx, tri), tot.as_dict()
 
 
-def oracle_trace(scene, width, height, ray_max_depth, x, y, iteration, sampler=S.JITTERED):
-    lib = oracle()
+def oracle_trace(scene, width, height, ray_max_depth, x, y, iteration, sampler=S.JITTERED, default_arithmetic=False):
+    lib = oracle(default_arithmetic)
     osc = OracleScene(scene, width, height, ray_max_depth, sampler)
     bounces = (PtoBounce * 64)()
     rad = (C.c_float * 4)()
