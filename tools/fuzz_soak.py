@@ -17,7 +17,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_ffi as O  # noqa: E402
 from opencl_pathtracer_amd import scenes, bvh_create, render_scene  # noqa: E402
 
-SPECS = {1: ("feat_64x64_d8", 64, 64, 8), 3: ("matmix_96x96_d8", 96, 96, 8)}
+from opencl_pathtracer_amd import structs as S  # noqa: E402
+
+# SOAK_MODE=uniform: the UNIFORM sampler's code objects; SOAK_MODE=ss: SUPER_SAMPLING (one light, no hostile records)
+MODE = os.environ.get("SOAK_MODE", "")
+SPECS = {"": {1: ("feat_64x64_d8", 64, 64, 8), 3: ("matmix_96x96_d8", 96, 96, 8)},
+         "uniform": {1: ("cornell_64x48_d4_uni", 64, 48, 4), 3: ("matmix_96x96_d8_uni", 96, 96, 8)},
+         "ss": {1: ("cornell_64x48_d4_ss", 64, 48, 4), 3: ("cornell_64x48_d4_ss", 64, 48, 4)}}[MODE]
+SAMPLER = S.UNIFORM if MODE == "uniform" else S.JITTERED
 
 
 def main():
@@ -25,11 +32,13 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     spp = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     warnings.simplefilter("ignore")
-    out = {"spp": spp, "scenes": [], "paths": 0, "mismatches": []}
+    out = {"spp": spp, "mode": MODE or "jittered", "scenes": [], "paths": 0, "mismatches": []}
     t0 = time.time()
     for seed in range(first, first + n):
         for suffix in ("", "h", "r", "hr", "t"):
-            n_lights = 1 if (seed + len(suffix)) % 2 else 3
+            n_lights = 1 if (seed + len(suffix)) % 2 or MODE == "ss" else 3
+            if MODE == "ss" and "h" in suffix:
+                continue
             case, w, h, d = SPECS[n_lights]
             tree = suffix == "t"
             name = f"fuzz{seed}{'' if tree else suffix}_l{n_lights}"
@@ -38,7 +47,7 @@ def main():
                 scenes.corrupt_tree(sc, seed)
             for strict in (False, True):
                 flags = 0 if strict else 16
-                ours = render_scene(sc, w, h, d, spp, flags=flags)
+                ours = render_scene(sc, w, h, d, spp, flags=flags, sampler=SAMPLER, super_sampling=MODE == "ss")
                 ref = O.ref_gpu_render(case, sc, w, h, d, spp, strict=strict)
                 same = (np.array_equal(ours[0].view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(ours[1], ref[1])
                         and all(np.array_equal(a, b) for a, b in zip(ours[2], ref[2])))
