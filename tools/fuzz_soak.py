@@ -19,11 +19,12 @@ from opencl_pathtracer_amd import scenes, bvh_create, render_scene  # noqa: E402
 
 from opencl_pathtracer_amd import structs as S  # noqa: E402
 
-# SOAK_MODE=uniform: the UNIFORM sampler's code objects; SOAK_MODE=ss: SUPER_SAMPLING (one light, no hostile records)
+# SOAK_MODE=fullsize: 1920 x 1080, depth 10, one light, default build only;  SOAK_MODE=uniform: the UNIFORM sampler's code objects; SOAK_MODE=ss: SUPER_SAMPLING (one light, no hostile records)
 MODE = os.environ.get("SOAK_MODE", "")
 SPECS = {"": {1: ("feat_64x64_d8", 64, 64, 8), 3: ("matmix_96x96_d8", 96, 96, 8)},
          "uniform": {1: ("cornell_64x48_d4_uni", 64, 48, 4), 3: ("matmix_96x96_d8_uni", 96, 96, 8)},
-         "ss": {1: ("cornell_64x48_d4_ss", 64, 48, 4), 3: ("cornell_64x48_d4_ss", 64, 48, 4)}}[MODE]
+         "ss": {1: ("cornell_64x48_d4_ss", 64, 48, 4), 3: ("cornell_64x48_d4_ss", 64, 48, 4)},
+         "fullsize": {1: ("tris1m_1920x1080_d10", 1920, 1080, 10), 3: ("tris1m_1920x1080_d10", 1920, 1080, 10)}}[MODE]
 SAMPLER = S.UNIFORM if MODE == "uniform" else S.JITTERED
 
 
@@ -36,7 +37,7 @@ def main():
     t0 = time.time()
     for seed in range(first, first + n):
         for suffix in ("", "h", "r", "hr", "t"):
-            n_lights = 1 if (seed + len(suffix)) % 2 or MODE == "ss" else 3
+            n_lights = 1 if (seed + len(suffix)) % 2 or MODE in ("ss", "fullsize") else 3
             if MODE == "ss" and "h" in suffix:
                 continue
             case, w, h, d = SPECS[n_lights]
@@ -45,7 +46,7 @@ def main():
             sc = bvh_create(scenes.build(name, w, h))
             if tree:
                 scenes.corrupt_tree(sc, seed)
-            for strict in (False, True):
+            for strict in ((False,) if MODE == "fullsize" else (False, True)):
                 flags = 0 if strict else 16
                 ours = render_scene(sc, w, h, d, spp, flags=flags, sampler=SAMPLER, super_sampling=MODE == "ss")
                 ref = O.ref_gpu_render(case, sc, w, h, d, spp, strict=strict)
