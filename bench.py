@@ -247,6 +247,8 @@ def main():
             "Mpaths/s": total["paths"] / elapsed / 1e6,
             "Mshadow_rays/s": total["shadow_rays"] / elapsed / 1e6,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
+            # paths whose ray was not a number at some bounce: given up by the launch and traced again by the literal loops (rank 0)
+            "paths_retraced": sched["paths_retraced"],
             "roofline": roof,
         }
         if sched["trips_node"]:

@@ -135,6 +135,8 @@ typedef struct ptmi_scheduler_stats {
     uint64_t cycles_path, cycles_loop;       /* shader-clock cycles, summed over waves: inside path-logic passes / in the main loop */
     uint64_t leaf_item_violations;           /* leaf passes: work items whose owner lane or triangle record index was out of range when a
                                                 lane read them (an item read before its writer: must be 0; checked only while collecting) */
+    uint64_t paths_retraced;                 /* paths a launch gave up because one of their rays was not a number, traced again by the
+                                                reference's literal loops (ptmi_literal_kernel_reason, below); counted ALWAYS, flag or not */
 } ptmi_scheduler_stats;
 
 /* The reference's device-side consistency checks: with -D LOG_INFO (OpenCL.cpp:310, globalVars.printLogInfos) its kernel

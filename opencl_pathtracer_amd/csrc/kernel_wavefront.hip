@@ -936,6 +936,7 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
             if (pc.tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[pc.tri], 1u);
         }
         // (the launch counted: one path, one segment, no hit)
+        atomicAdd(&block_counters[C_PATHS], 1ull);  // (here: paths traced again)
         atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)n_seg - 1ull);
         atomicAdd(&block_counters[C_HITS], (unsigned long long)depth);
         atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
@@ -943,7 +944,8 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
         atomicAdd(&block_counters[C_TRI], (unsigned long long)pc.tri);
     }
     __syncthreads();
-    if (tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
+    if (tid > C_PATHS && tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
+    if (tid == C_PATHS && block_counters[tid] != 0ull) atomicAdd(&sc.counters[C_RETRACED], block_counters[tid]);
 }
 
 // Histograms of the paths of one launch from their staged statistics words (FullKernel.cl:1319-1331: depth bin

@@ -1357,6 +1357,7 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
     out->trips_path = h[C_TRIPS_P]; out->lanes_path = h[C_LANES_P];
     out->cycles_path = h[C_CYCLES_P]; out->cycles_loop = h[C_CYCLES_LOOP];
     out->leaf_item_violations = h[C_ITEM_VIOLATIONS];
+    out->paths_retraced = h[C_RETRACED];
     return PTMI_OK;
 }
 
