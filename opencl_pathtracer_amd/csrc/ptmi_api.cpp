@@ -72,7 +72,11 @@ struct DeviceState {
     // else the slot of the last image that changed them (a device of a G-device render changes with every G-th image only, so
     // ptmi_render_snapshots copies 41.5 MB per OWN iteration instead of per image); -1 = the slot has never been filled.
     int source_slot[PTMI_MAX_SNAPSHOT_SLOTS];
-    uint32_t snapshot_gen[PTMI_MAX_SNAPSHOT_SLOTS] = {};  // bumped by every copy into the slot
+    // ... so d_snapshot[] / snapshot_ready[] / snapshot_gen[] are BUFFERS, source_slot[s] names the buffer ring slot s shows, and
+    // a buffer several slots show is never written: a new snapshot for one of them goes to a buffer no slot shows (there always
+    // is one: as many buffers as slots) - the others keep showing what they showed (tests/test_api_fuzz_gpu.py).
+    int buffer_refs[PTMI_MAX_SNAPSHOT_SLOTS] = {};
+    uint32_t snapshot_gen[PTMI_MAX_SNAPSHOT_SLOTS] = {};  // bumped by every copy into the buffer
     float* d_peer_copy = nullptr;      // devices[0] only: where device k's snapshot lands before the sum, one per device
     hipEvent_t peer_copied = nullptr;  // ... and the event that says it has
     int landed_slot = -1;              // ... and which snapshot it holds: (slot, generation) - a peer sends only what has changed
@@ -171,6 +175,7 @@ void free_scene_memory(ptmi_ctx* ctx)
             if (d.snapshot_ready[k]) (void)hipEventDestroy(d.snapshot_ready[k]);
             d.snapshot_ready[k] = nullptr;
             d.source_slot[k] = -1;
+            d.buffer_refs[k] = 0;
         }
         d.landed_slot = -1;
         if (d.d_peer_copy) (void)hipFree(d.d_peer_copy);
@@ -580,22 +585,41 @@ void device_share(uint32_t first, uint32_t n, uint32_t k, uint32_t G, uint32_t* 
     *n_k = skip < n ? (n - skip + G - 1) / G : 0;
 }
 
-// Queue, behind everything device `d` has been given so far, a copy of its accumulators into ring slot `slot`.
-int snapshot_device(ptmi_ctx* ctx, DeviceState& d, uint32_t slot)
+constexpr uint32_t kUserSlots = PTMI_MAX_SNAPSHOT_SLOTS - 1;  // the last slot is the library's own
+
+// Make ring slot `slot` of device `d` show buffer `b` (-1: nothing).
+void point_slot(DeviceState& d, uint32_t slot, int b)
+{
+    if (d.source_slot[slot] >= 0) d.buffer_refs[d.source_slot[slot]]--;
+    d.source_slot[slot] = b;
+    if (b >= 0) d.buffer_refs[b]++;
+}
+
+// Queue, behind everything device `d` has been given so far, a copy of its accumulators for ring slot `slot`: into the buffer
+// the slot shows if no other slot shows it too, else into one that no slot shows.  *buffer = where it went.
+int snapshot_device(ptmi_ctx* ctx, DeviceState& d, uint32_t slot, int* buffer = nullptr)
 {
     const size_t npix = ctx->npix();
     ON_DEVICE(ctx, d);
-    if (!d.d_snapshot[slot]) {
+    int b = d.source_slot[slot];
+    if (b < 0 || d.buffer_refs[b] > 1) {
+        b = d.buffer_refs[slot] == 0 ? (int)slot : -1;  // (its own, as long as nobody else has taken it)
+        for (int k = 0; b < 0 && k < (int)PTMI_MAX_SNAPSHOT_SLOTS; k++)
+            if (d.buffer_refs[k] == 0) b = k;
+        if (b < 0) return fail(ctx, PTMI_ERR_STATE, "snapshot ring: no free buffer");  // (cannot happen: as many buffers as slots)
+    }
+    if (!d.d_snapshot[b]) {
         void* p = nullptr;
         HIP_TRY(ctx, hipMalloc(&p, npix * 20));
-        d.d_snapshot[slot] = (float*)p;
+        d.d_snapshot[b] = (float*)p;
     }
-    if (!d.snapshot_ready[slot]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.snapshot_ready[slot], hipEventDisableTiming));
-    HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot], d.ds.image_color, npix * 16, hipMemcpyDeviceToDevice, d.stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[slot] + 4 * npix, d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToDevice, d.stream));
-    HIP_TRY(ctx, hipEventRecord(d.snapshot_ready[slot], d.stream));
-    d.source_slot[slot] = (int)slot;
-    d.snapshot_gen[slot]++;
+    if (!d.snapshot_ready[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.snapshot_ready[b], hipEventDisableTiming));
+    HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[b], d.ds.image_color, npix * 16, hipMemcpyDeviceToDevice, d.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d.d_snapshot[b] + 4 * npix, d.ds.image_ray_nb, npix * 4, hipMemcpyDeviceToDevice, d.stream));
+    HIP_TRY(ctx, hipEventRecord(d.snapshot_ready[b], d.stream));
+    point_slot(d, slot, b);
+    d.snapshot_gen[b]++;
+    if (buffer) *buffer = b;
     return PTMI_OK;
 }
 int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
@@ -614,20 +638,18 @@ int snapshot_all(ptmi_ctx* ctx, uint32_t slot)
 struct SnapshotPlan {
     uint32_t first, n, first_slot;
     uint32_t next = 0;    // next global k to provide on this device
-    int last_slot = -1;   // this device's latest copy of this call
+    int last_slot = -1;   // this device's latest copy of this call: the BUFFER it went to
     bool changed = true;  // accumulators changed since (or no copy of this call yet)
 };
-constexpr uint32_t kUserSlots = PTMI_MAX_SNAPSHOT_SLOTS - 1;  // the last slot is the library's own
 int snapshots_up_to(ptmi_ctx* ctx, DeviceState& d, SnapshotPlan& plan, uint32_t k_end)
 {
     for (; plan.next < k_end && plan.next < plan.n; plan.next++) {
         const uint32_t slot = (plan.first_slot + plan.next) % kUserSlots;
         if (plan.changed || plan.last_slot < 0) {
-            if (int rc = snapshot_device(ctx, d, slot)) return rc;
-            plan.last_slot = (int)slot;
+            if (int rc = snapshot_device(ctx, d, slot, &plan.last_slot)) return rc;
             plan.changed = false;
         } else {
-            d.source_slot[slot] = plan.last_slot;
+            point_slot(d, slot, plan.last_slot);
         }
     }
     return PTMI_OK;

@@ -1,0 +1,143 @@
+"""Random sequences of C-ABI calls against a model of what they mean (GPU).
+
+The calls of include/ptmi.h in random order - renders of arbitrary iteration ranges, snapshots into arbitrary ring slots, bursts
+(ptmi_render_snapshots), reads of the image / a slot / the statistics / the counters, clears, re-uploads, image writes - on one
+device and on one device listed two or three times (the in-library multi-device path with its lazy snapshots and incremental
+peer copies).  The model: the accumulators are the sum of the per-iteration images rendered since the last clear / upload /
+write, a slot holds the accumulators as they were when its snapshot was queued; the per-iteration images come from the CPU
+oracle.  One device: bit for bit.  Several: sample counts and statistics exactly, sums up to their association."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from opencl_pathtracer_amd import Backend, PtmiError, backend, structs as S
+
+pytestmark = pytest.mark.gpu
+W, H, D, N_IDS = 40, 30, 3, 48
+
+
+@pytest.fixture(scope="module")
+def per_iteration(scene_factory):
+    sc = scene_factory("cornell", W, H)
+    out = []
+    for k in range(N_IDS):
+        color, count, stats, totals = O.oracle_render(sc, W, H, D, 1, first_iteration=k, default_arithmetic=True)
+        out.append((color, count, stats, totals))
+    return sc, out
+
+
+class Model:
+    def __init__(self, per_it):
+        self.per_it = per_it
+        self.reset()
+        self.slots = {}
+
+    def reset(self):
+        self.color = np.zeros((H, W, 4), np.float32)
+        self.count = np.zeros((H, W), np.float32)
+        self.stats = [np.zeros(D + 1, np.int64), np.zeros(S.MAX_INTERSETCION_NUMBER, np.int64), np.zeros(S.MAX_INTERSETCION_NUMBER, np.int64)]
+        self.totals = None
+
+    def add(self, k):
+        c, n, st, tot = self.per_it[k]
+        self.color = self.color + c  # float32 adds, in call order: what a single device does
+        self.count = self.count + n
+        for a, b in zip(self.stats, st):
+            a += b
+        self.totals = dict(tot) if self.totals is None else {key: self.totals[key] + tot[key] for key in tot}
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]], ids=["one", "two", "three"])
+@pytest.mark.parametrize("seed", range(24))
+def test_random_call_sequences(seed, devices, per_iteration):
+    sc, per_it = per_iteration
+    rs = np.random.RandomState(1234 + seed)
+    exact = devices is None
+    be = Backend().setup_context(W, H, D, sc.lightsSize, S.JITTERED, flags=backend.FLAG_DEFAULT_ARITHMETIC, devices=devices)
+    m = Model(per_it)
+    ring = backend.USER_SNAPSHOT_SLOTS
+    few = ring if seed % 2 else 6  # (even seeds: six slots, so that snapshots overwrite each other - and the slots lazy copies point to - all the time)
+    log = []
+
+    def same_image(got, want_color, want_count, what):
+        color, count = got
+        history = f"{what}; calls so far: ... " + " ".join(str(c) for c in log[-40:])
+        if not np.array_equal(count, want_count):
+            raise AssertionError(f"sample counts {np.unique(count).tolist()} instead of {np.unique(want_count).tolist()}: " + history)
+        if exact and not np.array_equal(color.view(np.uint32), want_color.view(np.uint32)):
+            raise AssertionError("image bits differ: " + history)
+        if not exact and not np.allclose(color, want_color, rtol=3e-6, atol=1e-6):
+            raise AssertionError(f"image differs (max {float(np.abs(color - want_color).max())}): " + history)
+
+    try:
+        be.initialize_memory(sc)
+        for step in range(120):
+            op = rs.choice(["render", "render", "render", "snapshot", "burst", "read_slot", "read_slot", "read_image", "statistics",
+                            "counters", "clear", "upload", "write", "sync", "kernel_time", "display"])
+            if op == "render":
+                first, n = int(rs.randint(0, N_IDS - 6)), int(rs.choice([1, 1, 2, 3, 5]))
+                log.append(("render", first, n))
+                be.render(first, n)
+                for k in range(first, first + n):
+                    m.add(k)
+            elif op == "snapshot":
+                slot = int(rs.randint(0, few))
+                log.append(("snapshot", slot))
+                be.snapshot(slot)
+                m.slots[slot] = (m.color.copy(), m.count.copy())
+            elif op == "burst":
+                first, n, slot = int(rs.randint(0, N_IDS - 8)), int(rs.randint(1, 8)), int(rs.randint(0, few))
+                log.append(("burst", first, n, slot))
+                be.render_snapshots(first, n, slot)
+                for k in range(n):
+                    m.add(first + k)
+                    m.slots[(slot + k) % ring] = (m.color.copy(), m.count.copy())
+            elif op == "read_slot":
+                if m.slots:
+                    slot = int(rs.choice(sorted(m.slots)))
+                    log.append(("read_slot", slot))
+                    same_image(be.read_snapshot(slot), *m.slots[slot], f"slot {slot}")
+                else:
+                    with pytest.raises(PtmiError):
+                        be.read_snapshot(int(rs.randint(0, ring)))
+            elif op == "read_image":
+                log.append(("read_image",))
+                same_image(be.read_image(), m.color, m.count, "image")
+            elif op == "statistics":
+                log.append(("statistics",))
+                got = be.read_statistics()
+                assert all(np.array_equal(a.astype(np.int64), b) for a, b in zip(got, m.stats)), log[-12:]
+            elif op == "counters":
+                log.append(("counters",))
+                got = be.counters()
+                assert got == (m.totals or {k: 0 for k in got}), (got, m.totals, log[-12:])
+            elif op == "clear":
+                log.append(("clear",))
+                be.clear()
+                m.reset()
+            elif op == "upload":
+                log.append(("upload",))
+                be.initialize_memory(sc)
+                m.reset()
+                m.slots = {}
+            elif op == "write":
+                log.append(("write",))
+                color = rs.uniform(0, 4, (H, W, 4)).astype(np.float32)
+                count = np.full((H, W), float(rs.randint(0, 9)), np.float32)
+                be.write_image(color, count)
+                m.color, m.count = color.copy(), count.copy()
+            elif op == "sync":
+                be.synchronize()
+            elif op == "kernel_time":
+                ms, launches = be.kernel_time()
+                assert ms >= 0 and launches >= 0
+            else:
+                log.append(("display",))
+                got = be.read_display()
+                from opencl_pathtracer_amd import output
+                want = output.to_display_rgb(m.color, m.count)
+                if exact:
+                    assert np.array_equal(got[:, :3 * W].reshape(H, W, 3)[..., ::-1], want), log[-12:]
+        same_image(be.read_image(), m.color, m.count, "final image")
+    finally:
+        be.release()
