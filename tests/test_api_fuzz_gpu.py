@@ -16,14 +16,22 @@ pytestmark = pytest.mark.gpu
 W, H, D, N_IDS = 40, 30, 3, 48
 
 
+SCENES = ["cornell", "fuzz3_l1", "fuzz5h_l1", "fuzz41hr_l1"]  # (one light each; the last two hold NaN-distance records: literal kernel)
+
+
 @pytest.fixture(scope="module")
-def per_iteration(scene_factory):
-    sc = scene_factory("cornell", W, H)
-    out = []
-    for k in range(N_IDS):
-        color, count, stats, totals = O.oracle_render(sc, W, H, D, 1, first_iteration=k, default_arithmetic=True)
-        out.append((color, count, stats, totals))
-    return sc, out
+def per_iteration():
+    """{(scene name, default arithmetic?): (scene, [per-iteration (color, count, statistics, totals) from the oracle])}"""
+    import warnings
+    from opencl_pathtracer_amd import scenes, bvh_create
+    out = {}
+    for name in SCENES:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sc = bvh_create(scenes.build(name, W, H))
+        for da in (False, True):
+            out[name, da] = (sc, [O.oracle_render(sc, W, H, D, 1, first_iteration=k, default_arithmetic=da) for k in range(N_IDS)])
+    return out
 
 
 class Model:
@@ -50,11 +58,16 @@ class Model:
 @pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]], ids=["one", "two", "three"])
 @pytest.mark.parametrize("seed", range(24))
 def test_random_call_sequences(seed, devices, per_iteration):
-    sc, per_it = per_iteration
     rs = np.random.RandomState(1234 + seed)
     exact = devices is None
-    be = Backend().setup_context(W, H, D, sc.lightsSize, S.JITTERED, flags=backend.FLAG_DEFAULT_ARITHMETIC, devices=devices)
+    da = seed % 3 != 0
+    flags = (backend.FLAG_DEFAULT_ARITHMETIC if da else 0) | (backend.FLAG_MEGAKERNEL if seed % 5 == 4 else 0)
+    bursts = not flags & backend.FLAG_MEGAKERNEL  # (ptmi_render_snapshots wants the wavefront kernel - or a scene that forces the other)
+    sc, per_it = per_iteration[SCENES[0], da]
+    be = Backend().setup_context(W, H, D, sc.lightsSize, S.JITTERED, flags=flags, devices=devices)
     m = Model(per_it)
+    pinned = [np.empty((H, W, 4), np.float32), np.empty((H, W), np.float32)]
+    is_pinned = False
     ring = backend.USER_SNAPSHOT_SLOTS
     few = ring if seed % 2 else 6  # (even seeds: six slots, so that snapshots overwrite each other - and the slots lazy copies point to - all the time)
     log = []
@@ -73,7 +86,11 @@ def test_random_call_sequences(seed, devices, per_iteration):
         be.initialize_memory(sc)
         for step in range(120):
             op = rs.choice(["render", "render", "render", "snapshot", "burst", "read_slot", "read_slot", "read_image", "statistics",
-                            "counters", "clear", "upload", "write", "sync", "kernel_time", "display"])
+                            "counters", "clear", "upload", "write", "sync", "kernel_time", "display", "pin"])
+            if op == "burst" and not bursts:
+                with pytest.raises(PtmiError):
+                    be.render_snapshots(0, 2, 0)
+                continue
             if op == "render":
                 first, n = int(rs.randint(0, N_IDS - 6)), int(rs.choice([1, 1, 2, 3, 5]))
                 log.append(("render", first, n))
@@ -96,13 +113,13 @@ def test_random_call_sequences(seed, devices, per_iteration):
                 if m.slots:
                     slot = int(rs.choice(sorted(m.slots)))
                     log.append(("read_slot", slot))
-                    same_image(be.read_snapshot(slot), *m.slots[slot], f"slot {slot}")
+                    same_image(be.read_snapshot(slot, out=pinned if rs.rand() < 0.5 else None), *m.slots[slot], f"slot {slot}")
                 else:
                     with pytest.raises(PtmiError):
                         be.read_snapshot(int(rs.randint(0, ring)))
             elif op == "read_image":
                 log.append(("read_image",))
-                same_image(be.read_image(), m.color, m.count, "image")
+                same_image(be.read_image(out=pinned if rs.rand() < 0.5 else None), m.color, m.count, "image")
             elif op == "statistics":
                 log.append(("statistics",))
                 got = be.read_statistics()
@@ -116,16 +133,23 @@ def test_random_call_sequences(seed, devices, per_iteration):
                 be.clear()
                 m.reset()
             elif op == "upload":
-                log.append(("upload",))
+                name = SCENES[int(rs.randint(0, len(SCENES)))]
+                log.append(("upload", name))
+                sc, per_it = per_iteration[name, da]
                 be.initialize_memory(sc)
-                m.reset()
-                m.slots = {}
+                assert (be.literal_kernel_reason() is not None) == (name.startswith("fuzz") and "h" in name.split("_")[0])
+                m = Model(per_it)
             elif op == "write":
                 log.append(("write",))
                 color = rs.uniform(0, 4, (H, W, 4)).astype(np.float32)
                 count = np.full((H, W), float(rs.randint(0, 9)), np.float32)
                 be.write_image(color, count)
                 m.color, m.count = color.copy(), count.copy()
+            elif op == "pin":
+                log.append(("pin", not is_pinned))
+                for a in pinned:
+                    (be.unpin_host_buffer if is_pinned else be.pin_host_buffer)(a)
+                is_pinned = not is_pinned
             elif op == "sync":
                 be.synchronize()
             elif op == "kernel_time":
