@@ -974,7 +974,7 @@ static int kernel_main_impl(const pto_scene* sc, uint32_t gx, uint32_t gy, uint3
         out->image_ray_nb[off] = n_after;
         memcpy(&out->image_color[4 * off], &after, 16);
         if (out->image_v) {
-            if (iteration == 0) {
+            if (iteration == 0 || (sc->first_sample_guard && n_before == 0.f)) {
                 memset(&out->image_v[4 * off], 0, 16);
             } else {
                 f4 v;

@@ -58,6 +58,9 @@ typedef struct pto_scene {
     const float* x2inv;     /* 1001-entry table (Kernel/X2inv.cl), only if super_sampling */
     uint32_t russian_roulette; /* the block the reference keeps commented out (cl:1306-1314, RUSSIAN_ROULETTE false): non-parity mode */
     uint32_t source_seed;      /* non-parity mode: InitializeRandomSeed's zero test on the SQUARE, as the source reads (h:255-264) */
+    uint32_t first_sample_guard; /* SUPER_SAMPLING, the product's one guard: a pixel's FIRST sample has no deviation whatever the
+                                  * iteration id (the reference divides 0 by 0 when a render does not start at iteration 0, cl:1349,
+                                  * and keeps a NaN variance for good); with it the oracle models a render that starts anywhere */
 } pto_scene;
 
 /* Output buffers, caller-allocated; accumulated into (not zeroed here). */

@@ -33,7 +33,8 @@ class PtoScene(C.Structure):
                 ("camera_position", F4), ("camera_direction", F4), ("camera_right", F4), ("camera_up", F4),
                 ("image_width", C.c_uint32), ("image_height", C.c_uint32), ("ray_max_depth", C.c_uint32),
                 ("lights_size", C.c_uint32), ("sampler", C.c_uint32), ("super_sampling", C.c_uint32),
-                ("x2inv", C.c_void_p), ("russian_roulette", C.c_uint32), ("source_seed", C.c_uint32)]
+                ("x2inv", C.c_void_p), ("russian_roulette", C.c_uint32), ("source_seed", C.c_uint32),
+                ("first_sample_guard", C.c_uint32)]
 
 
 class PtoBuffers(C.Structure):
@@ -144,7 +145,7 @@ class OracleScene:
     """Keeps the numpy arrays alive next to the C struct that points into them."""
 
     def __init__(self, scene, width, height, ray_max_depth, sampler=S.JITTERED, super_sampling=False, russian_roulette=False,
-                 source_seed=False):
+                 source_seed=False, first_sample_guard=False):
         self.arrays = [np.ascontiguousarray(a) for a in (scene.bvh, scene.triangulation, scene.lights, scene.materiaux,
                                                          scene.textures, scene.texturesData, scene.sky)]
         s = PtoScene()
@@ -159,17 +160,18 @@ class OracleScene:
             s.super_sampling, s.x2inv = 1, self.x2inv.ctypes.data_as(C.c_void_p)
         s.russian_roulette = 1 if russian_roulette else 0
         s.source_seed = 1 if source_seed else 0
+        s.first_sample_guard = 1 if first_sample_guard else 0
         self.c = s
         self.width, self.height, self.depth = width, height, ray_max_depth
 
 
 def oracle_render(scene, width, height, ray_max_depth, n_iterations, first_iteration=0, sampler=S.JITTERED,
                   n_threads=8, into=None, super_sampling=False, image_v=None, russian_roulette=False, default_arithmetic=False,
-                  source_seed=False):
+                  source_seed=False, first_sample_guard=False):
     """Returns (imageColor[H,W,4], imageRayNb[H,W], (depths, bbx, tri), totals dict).  `into` = a previous
     result tuple to keep accumulating into (iteration ranges must then be rendered in order)."""
     lib = oracle(default_arithmetic)
-    osc = OracleScene(scene, width, height, ray_max_depth, sampler, super_sampling, russian_roulette, source_seed)
+    osc = OracleScene(scene, width, height, ray_max_depth, sampler, super_sampling, russian_roulette, source_seed, first_sample_guard)
     if into is None:
         color = np.zeros((height, width, 4), np.float32)
         count = np.zeros((height, width), np.float32)

@@ -165,3 +165,81 @@ def test_random_call_sequences(seed, devices, per_iteration):
         same_image(be.read_image(), m.color, m.count, "final image")
     finally:
         be.release()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_call_sequences_super_sampling(seed, per_iteration):
+    """The same for an adaptive (SUPER_SAMPLING) context, whose every iteration depends on the accumulators and the variance
+    image it finds: renders of arbitrary iteration ids, variance reads, saved states written back (resume), snapshots, clears,
+    re-uploads.  The model is the oracle run statefully on the same arrays.  Bit for bit."""
+    rs = np.random.RandomState(99 + seed)
+    da = seed % 2 == 0
+    name = ["cornell", "fuzz3_l1"][seed % 4 == 3]
+    sc = per_iteration[name, da][0]
+    be = Backend().setup_context(W, H, D, sc.lightsSize, S.JITTERED, super_sampling=True, flags=backend.FLAG_DEFAULT_ARITHMETIC if da else 0)
+
+    def fresh():
+        return {"color": np.zeros((H, W, 4), np.float32), "count": np.zeros((H, W), np.float32), "v": np.zeros((H, W, 4), np.float32),
+                "stats": (np.zeros(D + 1, np.uint32), np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32), np.zeros(S.MAX_INTERSETCION_NUMBER, np.uint32)),
+                "totals": None}
+
+    m, saved, slots, log = fresh(), None, {}, []
+
+    def check(cond, what):
+        if not cond:
+            raise AssertionError(what + "; calls so far: ... " + " ".join(str(c) for c in log[-40:]))
+
+    try:
+        be.initialize_memory(sc)
+        for step in range(70):
+            op = rs.choice(["render", "render", "render", "read_image", "variance", "statistics", "counters", "clear", "save", "resume",
+                            "snapshot", "read_slot", "upload"])
+            if op == "render":
+                first, n = int(rs.randint(0, 40)), int(rs.choice([1, 2, 4, 9]))
+                log.append(("render", first, n))
+                be.render(first, n)
+                _, _, _, tot = O.oracle_render(sc, W, H, D, n, first_iteration=first, super_sampling=True, default_arithmetic=da,
+                                               first_sample_guard=True, into=(m["color"], m["count"], m["stats"], None), image_v=m["v"])
+                m["totals"] = dict(tot) if m["totals"] is None else {k: m["totals"][k] + tot[k] for k in tot}
+            elif op == "read_image":
+                log.append(("read_image",))
+                color, count = be.read_image()
+                check(np.array_equal(count, m["count"]), "sample counts differ")
+                check(np.array_equal(color.view(np.uint32), m["color"].view(np.uint32)), "image bits differ")
+            elif op == "variance":
+                log.append(("variance",))
+                check(np.array_equal(be.read_variance().view(np.uint32), m["v"].view(np.uint32)), "variance image bits differ")
+            elif op == "statistics":
+                log.append(("statistics",))
+                check(all(np.array_equal(a, b) for a, b in zip(be.read_statistics(), m["stats"])), "histograms differ")
+            elif op == "counters":
+                got = be.counters()
+                check(got == (m["totals"] or {k: 0 for k in got}), f"counters {got} instead of {m['totals']}")
+            elif op == "clear":
+                log.append(("clear",))
+                be.clear()
+                m = fresh()
+            elif op == "save":
+                log.append(("save",))
+                saved = (m["color"].copy(), m["count"].copy(), m["v"].copy())
+            elif op == "resume" and saved is not None:
+                log.append(("resume",))
+                be.write_image(saved[0], saved[1])
+                be.write_variance(saved[2])
+                m["color"], m["count"], m["v"] = saved[0].copy(), saved[1].copy(), saved[2].copy()
+            elif op == "snapshot":
+                slot = int(rs.randint(0, 5))
+                log.append(("snapshot", slot))
+                be.snapshot(slot)
+                slots[slot] = (m["color"].copy(), m["count"].copy())
+            elif op == "read_slot" and slots:
+                slot = int(rs.choice(sorted(slots)))
+                log.append(("read_slot", slot))
+                color, count = be.read_snapshot(slot)
+                check(np.array_equal(count, slots[slot][1]) and np.array_equal(color.view(np.uint32), slots[slot][0].view(np.uint32)), f"slot {slot} differs")
+            elif op == "upload":
+                log.append(("upload",))
+                be.initialize_memory(sc)
+                m, slots = fresh(), {}
+    finally:
+        be.release()
