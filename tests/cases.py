@@ -22,9 +22,24 @@ FEATURE_SPP = 8
 # scenes.fuzz_scene / corrupt_records scenes whose reference results (both builds) are committed as digests
 # (tests/golden/ref_fuzz.npz): h = hostile records (NaN distances), r = records no importer writes, _l<n> = lights.
 # 1 light -> code object feat_64x64_d8, 3 lights -> matmix_96x96_d8
+# t = scenes.corrupt_tree on the built tree
 FUZZ_FIXTURES = ["fuzz0_l1", "fuzz0h_l1", "fuzz1_l3", "fuzz1h_l3", "fuzz2_l1", "fuzz3_l1", "fuzz5h_l1", "fuzz7h_l3", "fuzz40r_l1", "fuzz41hr_l1",
-                 "fuzz42r_l3", "fuzz43hr_l3", "fuzz46r_l1", "fuzz47hr_l3"]
+                 "fuzz42r_l3", "fuzz43hr_l3", "fuzz46r_l1", "fuzz47hr_l3", "fuzz60t_l1", "fuzz61rt_l3", "fuzz63ht_l1", "fuzz67rt_l1"]
 FUZZ_CASE = {1: ("feat_64x64_d8", 64, 64, 8), 3: ("matmix_96x96_d8", 96, 96, 8)}
+
+
+def build_fuzz(name, w, h):
+    """A FUZZ_FIXTURES scene with its tree: scenes.build + the product's BVH builder (+ scenes.corrupt_tree for a `t` name)."""
+    import re
+    import warnings
+    from opencl_pathtracer_amd import scenes, bvh_create
+    m = re.fullmatch(r"fuzz(\d+)(h?)(r?)(t?)_l(\d+)", name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (the hostile scenes divide 0 by 0 on purpose, as the importer would)
+        sc = bvh_create(scenes.build(f"fuzz{m.group(1)}{m.group(2)}{m.group(3)}_l{m.group(5)}", w, h))
+        if m.group(4):
+            scenes.corrupt_tree(sc, int(m.group(1)))
+    return sc
 
 
 def result_digest(color, count, depths, bbx, tri):

@@ -36,7 +36,7 @@ def scene_digest(sc):
 def full_scene_digest(sc):
     """Every byte the kernel can read (the fuzzed scenes vary all of it)."""
     h = hashlib.sha256(scene_digest(sc).encode())
-    for a in (sc.triangulation, sc.lights, sc.materiaux, sc.textures, sc.texturesData, sc.sky, sc.cameraPosition, sc.cameraDirection,
+    for a in (sc.bvh["trianglesAABB"]["isEmpty"], sc.bvh["cutAxis"], sc.bvh["isLeaf"], sc.triangulation, sc.lights, sc.materiaux, sc.textures, sc.texturesData, sc.sky, sc.cameraPosition, sc.cameraDirection,
               sc.cameraRight, sc.cameraUp):
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
@@ -51,9 +51,7 @@ def fuzz_fixtures(out_dir):
         if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
             print("skip", name, "(no code object)")
             continue
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            sc = bvh_create(scenes.build(name, w, h))
+        sc = cases.build_fuzz(name, w, h)
         digests[name + "_scene"] = full_scene_digest(sc)
         for strict, key in ((True, name), (False, name + "_default")):
             color, count, (dep, bbx, tri), _ = O.ref_gpu_render(case, sc, w, h, d, cases.FEATURE_SPP, strict=strict)

@@ -177,9 +177,7 @@ def test_oracle_equals_both_reference_builds_on_fuzzed_scenes(built):
     spec.loader.exec_module(mk)
     for name in cases.FUZZ_FIXTURES:
         _, w, h, d = cases.FUZZ_CASE[int(name.rsplit("_l", 1)[1])]
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            sc = bvh_create(scenes.build(name, w, h))
+        sc = cases.build_fuzz(name, w, h)
         assert str(fx[name + "_scene"]) == mk.full_scene_digest(sc), f"{name}: scene generator changed since the fixture was made"
         for da, key in ((False, name), (True, name + "_default")):
             color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.FEATURE_SPP, default_arithmetic=da)
