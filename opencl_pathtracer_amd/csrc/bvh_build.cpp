@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
+#include <string>
 #include <cstring>
 #include <vector>
 
@@ -95,6 +97,7 @@ struct Builder {
     ptmi_bounding_box l2r_box[3][kBins], r2l_box[3][kBins];
     int l2r_count[3][kBins], r2l_count[3][kBins];
     float k1[3] = { 0, 0, 0 };
+    bool failed = false;  // a centroid fell outside its node's bins
 
     void make_node(uint32_t idx, uint32_t start, uint32_t count, const ptmi_bounding_box& tri_box,
                    const ptmi_bounding_box& cen_box)
@@ -120,6 +123,9 @@ struct Builder {
     uint32_t build(uint32_t idx)
     {
         ptmi_node* N = &nodes[idx];
+        // (boxes whose extents overflow make the cost comparisons meaningless - a split can then leave a side empty and never end;
+        // a tree this deep is of no use to the integrator either: PTMI_BVH_MAX_DEPTH)
+        if (failed || depth > 8 * PTMI_BVH_MAX_DEPTH) { failed = true; return idx + 1; }
 
         if (N->nb_triangles <= kLeafMaxSize) return make_leaf(idx, PTMI_NODE_LEAF_MAX_SIZE);
         {
@@ -146,7 +152,11 @@ struct Builder {
 
             const float lo = axis_of(cmin, axis);
             for (int i = first; i <= last; i++) {
-                const int bin = (int)(k1[axis] * (axis_of(tris[i].aabb.centroid, axis) - lo));
+                const float scaled = k1[axis] * (axis_of(tris[i].aabb.centroid, axis) - lo);
+                // (the reference ASSERTs triangleBin < const__K, BVH.cpp:199, and indexes out of bounds without it: centroids so
+                // far apart that their difference overflows - the entry point below already refuses non-finite ones)
+                if (!(scaled >= 0.0f && scaled < (float)kBins)) { failed = true; return idx + 1; }
+                const int bin = (int)scaled;
                 bin_count[axis][bin]++;
                 unite(bin_box[axis][bin], tris[i].aabb);
             }
@@ -226,6 +236,17 @@ extern "C" int ptmi_bvh_create(ptmi_triangle* triangulation, uint32_t n, ptmi_no
         ptmi_internal::set_global_error("ptmi_bvh_create: null array or empty triangulation");
         return PTMI_ERR_INVALID_ARGUMENT;
     }
+    // The reference's builder has no defined behaviour for boxes that are not numbers (its bin ASSERT fires, BVH.cpp:199; without
+    // assertions it writes out of bounds): an error code here.
+    for (uint32_t i = 0; i < n; i++) {
+        const ptmi_bounding_box& a = triangulation[i].aabb;
+        const float v[9] = {a.p_min.x, a.p_min.y, a.p_min.z, a.p_max.x, a.p_max.y, a.p_max.z, a.centroid.x, a.centroid.y, a.centroid.z};
+        for (float f : v)
+            if (!std::isfinite(f)) {
+                ptmi_internal::set_global_error("ptmi_bvh_create: triangle " + std::to_string(i) + " has a bounding box that is not finite");
+                return PTMI_ERR_BAD_SCENE;
+            }
+    }
     // BVH_Create, BVH.cpp:12-37
     ptmi_bounding_box full_tri, full_cen;
     std::memset(&full_tri, 0, sizeof full_tri);
@@ -242,6 +263,10 @@ extern "C" int ptmi_bvh_create(ptmi_triangle* triangulation, uint32_t n, ptmi_no
     b.make_node(0, 0, n, full_tri, full_cen);
     b.size = 1;
     b.build(0);
+    if (b.failed) {
+        ptmi_internal::set_global_error("ptmi_bvh_create: bounding boxes too large to build a tree from (their extents overflow)");
+        return PTMI_ERR_BAD_SCENE;
+    }
     if (bvh_size) *bvh_size = b.size;
     if (bvh_max_depth) *bvh_max_depth = b.max_depth;
     return PTMI_OK;

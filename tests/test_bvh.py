@@ -132,6 +132,34 @@ def test_fuzzed_scenes_match_reference_builder(seed, built):
         assert_same_tree(ref_nodes, ref_tris, ref_depth, sc)
 
 
+@pytest.mark.parametrize("value", [np.nan, np.inf, -np.inf, 3e38])
+def test_boxes_that_are_not_numbers_are_an_error_not_a_fault(value, built):
+    """The reference's builder ASSERTs on them (BVH.cpp:199: a bin index out of range; without assertions it writes out of
+    bounds).  The product's refuses non-finite boxes outright; with finite but overflowing ones (3e38) it either builds a tree
+    (a usable one: every triangle in one leaf) or refuses - it never faults."""
+    import warnings
+    for seed in range(1, 7):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sc = scenes.build(f"fuzz{seed}_l1", 64, 64)
+        rs = np.random.RandomState(seed)
+        t = sc.triangulation
+        for i in rs.choice(len(t), max(1, len(t) // 20), replace=False):
+            t["AABB"][rs.choice(["pMin", "pMax", "centroid"])][i][int(rs.randint(0, 3))] = value
+        if np.isfinite(value):
+            try:
+                bvh_create(sc)
+            except PtmiError as e:
+                assert e.code == -5 and "overflow" in str(e)
+                continue
+            leaves = sc.bvh[sc.bvh["isLeaf"] != 0]
+            assert leaves["nbTriangles"].sum() == len(t) and sorted(sc.triangulation["id"].tolist()) == list(range(len(t)))
+        else:
+            with pytest.raises(PtmiError, match="not finite") as e:
+                bvh_create(sc)
+            assert e.value.code == -5
+
+
 def test_empty_triangulation_is_an_error(built):
     sc = scenes.cornell_box(8, 8)
     sc.triangulation = np.zeros(0, S.Triangle)
