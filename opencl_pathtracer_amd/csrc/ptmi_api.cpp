@@ -341,6 +341,14 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
         const ptmi_triangle& t = sc->triangulation[i];
         if (t.mat_pos >= sc->materiaux_size || t.mat_neg >= sc->materiaux_size)
             return fail(ctx, PTMI_ERR_BAD_SCENE, "triangle " + std::to_string(i) + " references a material out of range");
+        if (!sc->materiaux[t.mat_pos].is_simple_color || !sc->materiaux[t.mat_neg].is_simple_color) {
+            // texture coordinates index texels (header.cl:430-459: u - (int)u, then (uint)(u * (width - 1))): beyond the int range the
+            // wrap does nothing and the index leaves the texture - in the reference as well, which reads whatever is there
+            const float* uv = reinterpret_cast<const float*>(&t.uvp1);
+            for (int k = 0; k < 12; k++)
+                if (!(std::fabs(uv[k]) <= 0x1p+30f))
+                    return fail(ctx, PTMI_ERR_BAD_SCENE, "triangle " + std::to_string(i) + " has texture coordinates that are not finite (or beyond 2^30)");
+        }
         DTri& d = out.tris[i];
         std::memcpy(d.s1, &t.s1, 16); std::memcpy(d.s2, &t.s2, 16); std::memcpy(d.s3, &t.s3, 16);
         std::memcpy(d.n, &t.n, 16);

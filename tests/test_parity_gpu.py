@@ -477,6 +477,20 @@ def test_bad_scene_is_an_error_not_a_fault(scene_factory):
     with pytest.raises(PtmiError):
         be.render(0, 1)  # no scene resident
     be.release()
+    # texture coordinates beyond the int range would index texels outside the texture (header.cl:430-459): refused for textured triangles
+    from opencl_pathtracer_amd import scenes, bvh_create
+    tex = bvh_create(scenes.build("feat_textured", 64, 64))
+    textured = np.flatnonzero(tex.materiaux["isSimpleColor"][tex.triangulation["materialWithPositiveNormalIndex"]] == 0)
+    plain = np.flatnonzero(tex.materiaux["isSimpleColor"][tex.triangulation["materialWithPositiveNormalIndex"]] != 0)
+    be = Backend().setup_context(64, 64, 4, 1)
+    tex.triangulation["UVP2"][plain[0]] = (1e30, np.inf)  # an untextured triangle's coordinates are never read: fine
+    be.initialize_memory(tex)
+    for bad in (1e30, np.inf, np.nan):
+        tex.triangulation["UVN3"][textured[0]] = (0.5, bad)
+        with pytest.raises(PtmiError, match="texture coordinates") as e:
+            be.initialize_memory(tex)
+        assert e.value.code == -5
+    be.release()
 
 
 @pytest.mark.parametrize("case", list(cases.CASES))
