@@ -15,7 +15,23 @@
 using namespace PathTracerNS;
 
 static int g_callbacks = 0;
-static bool update_window() { g_callbacks++; return true; }
+static const GlobalVars* g_gv = nullptr;
+static std::vector<uint64_t> g_shown;  // what the viewer saw at each callback: FNV-1a over imageColor, then over imageRayNb
+static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+static bool update_window()
+{
+    g_callbacks++;
+    if (g_gv) {
+        g_shown.push_back(fnv(g_gv->imageColor, sizeof(RGBAColor) * (size_t)g_gv->imageSize));
+        g_shown.push_back(fnv(g_gv->imageRayNb, sizeof(float) * (size_t)g_gv->imageSize));
+    }
+    return true;
+}
 
 template <class T>
 static bool rd(FILE* f, T* p, size_t n) { return n == 0 || std::fread(p, sizeof(T), n, f) == n; }
@@ -52,6 +68,7 @@ int main(int argc, char** argv)
     gv.imageColor = color.data(); gv.imageRayNb = count.data();
     gv.rayDepths = depths.data(); gv.rayIntersectedBBx = bbx.data(); gv.rayIntersectedTri = tri.data();
     double t1 = 0, t2 = 0, t3 = 0;
+    g_gv = &gv;
     gv.printLogInfos = std::getenv("SHIM_DRIVER_LOG_INFO") != nullptr;  // the reference's -D LOG_INFO switch (OpenCL.cpp:310)
     try {
         BVH_Create(gv);
@@ -72,6 +89,9 @@ int main(int argc, char** argv)
     std::fwrite(depths.data(), 4, depths.size(), o);
     std::fwrite(bbx.data(), 4, bbx.size(), o);
     std::fwrite(tri.data(), 4, tri.size(), o);
+    const uint64_t n_shown = g_shown.size();  // trailer: the hashes of the images shown, in callback order
+    std::fwrite(&n_shown, 8, 1, o);
+    std::fwrite(g_shown.data(), 8, g_shown.size(), o);
     std::fclose(o);
     delete[] gv.bvh;
     return 0;

@@ -47,6 +47,22 @@ def read_result(path, w, h, depth):
     return meta, color, count, dep, bbx, tri
 
 
+def read_shown(path, w, h, depth):
+    """The trailer of the driver's result file: [(hash of imageColor, hash of imageRayNb) at every callback]."""
+    raw = open(path, "rb").read()
+    off = 12 + w * h * 20 + (depth + 1) * 4 + 40000
+    n = struct.unpack_from("<Q", raw, off)[0]
+    v = np.frombuffer(raw, np.uint64, n, off + 8)
+    return [(int(v[2 * i]), int(v[2 * i + 1])) for i in range(n // 2)]
+
+
+def fnv(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
 def test_mirror_header_layout_equals_reference(tmp_path):
     """include/pathtracer_backend.hpp must be binary-identical to the reference's GlobalVars and scene structs,
@@ -187,3 +203,48 @@ def test_reference_orchestration_renders(env, tmp_path):
         assert np.allclose(color, o_color, rtol=2e-6, atol=1e-6)
     else:
         assert np.array_equal(color.view(np.uint32), o_color.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_every_image_the_viewer_sees_under_random_loop_settings(seed, driver, tmp_path):
+    """OpenCL_RunKernel under random settings of its loop (burst length, look-ahead, images per launch, one device listed one to
+    three times, any number of images): the callback must find in imageColor / imageRayNb exactly the image of the reference's
+    blocking loop at that point - hashed at every callback by the driver and compared with the oracle's running sums (one device,
+    one image per launch: bit for bit; otherwise the sample counts, and the final image up to the association of the sums)."""
+    rs = np.random.RandomState(4242 + seed)
+    w, h, d = 48, 36, 3
+    n = int(rs.randint(1, 45))
+    env = {}
+    if rs.rand() < 0.7:
+        env["PTMI_BURST"] = str(int(rs.choice([1, 2, 3, 5, 16, 40])))
+    if rs.rand() < 0.5:
+        env["PTMI_LOOKAHEAD"] = str(int(rs.choice([0, 1, 2, 5, 70])))
+    batch = int(rs.choice([1, 1, 1, 2, 3]))
+    if batch > 1:
+        env["PTMI_IMAGES_PER_LAUNCH"] = str(batch)
+    devices = int(rs.choice([1, 1, 2, 3]))
+    if devices > 1:
+        env["PTMI_DEVICES"] = ",".join(["0"] * devices)
+    sc = scenes.build("cornell", w, h)
+    scene_file, out_file = str(tmp_path / "s.bin"), str(tmp_path / "o.bin")
+    dump_scene(scene_file, sc, w, h, d, S.JITTERED, n)
+    r = subprocess.run([driver, scene_file, out_file], capture_output=True, text=True, env={**os.environ, **env})
+    assert r.returncode == 0, (env, r.stderr)
+    (callbacks, _, _), color, count, dep, bbx, tri = read_result(out_file, w, h, d)
+    shown = read_shown(out_file, w, h, d)
+    steps = (n + batch - 1) // batch
+    assert callbacks == steps == len(shown), (env, n, callbacks)
+    ref = bvh_create(scenes.build("cornell", w, h))
+    acc = None
+    for k in range(steps):
+        first, m = k * batch, min(batch, n - k * batch)
+        acc = O.oracle_render(ref, w, h, d, m, first_iteration=first, default_arithmetic=True, into=acc)
+        assert shown[k][1] == fnv(acc[1]), (env, n, f"sample counts shown at callback {k}")
+        if devices == 1:
+            assert shown[k][0] == fnv(acc[0]), (env, n, f"image shown at callback {k}")
+    assert np.array_equal(count, acc[1]) and all(np.array_equal(a, b) for a, b in zip((dep, bbx, tri), acc[2]))
+    if devices == 1:
+        assert np.array_equal(color.view(np.uint32), acc[0].view(np.uint32)), (env, n)
+    else:
+        assert np.allclose(color, acc[0], rtol=3e-6, atol=1e-6), (env, n)
