@@ -114,7 +114,9 @@ def test_every_feature_bit_exact_vs_reference_default_build(feature):
     _assert_equal_to_reference(render_scene(sc, w, h, d, 256, flags=DA), ref, feature)
 
 
-FULL_SIZE = {"tris1m_1920x1080_d10": ("tris1m", S.JITTERED, 1920, 1080, 10, 2),   # BASELINE configs[2]: the bench workload
+FULL_SIZE = {"cornell_512x512_d4": ("cornell", S.JITTERED, 512, 512, 4, 8),          # BASELINE configs[0]
+             "matmix_3840x2160_d16": ("matmix", S.JITTERED, 3840, 2160, 16, 1),     # the stand-in for configs[4]: 4K, 16 bounces, 3 lights
+             "tris1m_1920x1080_d10": ("tris1m", S.JITTERED, 1920, 1080, 10, 2),   # BASELINE configs[2]: the bench workload
              "cornell_1920x1080_d8": ("cornell", S.JITTERED, 1920, 1080, 8, 4)}     # BASELINE configs[1]
 
 
