@@ -243,3 +243,43 @@ def test_random_call_sequences_super_sampling(seed, per_iteration):
                 m, slots = fresh(), {}
     finally:
         be.release()
+
+
+def test_two_contexts_driven_from_two_threads(per_iteration):
+    """Contexts share nothing a caller can see: two of them - different scenes, arithmetics and kernels - driven at the same time
+    from two host threads (ctypes releases the interpreter lock inside the calls) produce what each produces alone."""
+    import threading
+    jobs = [("cornell", True, 0), ("fuzz3_l1", False, 0), ("fuzz5h_l1", True, 0), ("cornell", False, backend.FLAG_MEGAKERNEL)]
+    results, errors = {}, []
+
+    def drive(i, name, da, extra):
+        try:
+            sc, per_it = per_iteration[name, da]
+            be = Backend().setup_context(W, H, D, sc.lightsSize, S.JITTERED, flags=(backend.FLAG_DEFAULT_ARITHMETIC if da else 0) | extra)
+            try:
+                be.initialize_memory(sc)
+                for rep in range(6):
+                    be.render(rep * 5, 5)
+                    if rep % 2:
+                        be.read_image()
+                color, count = be.read_image()
+                results[i] = (color.copy(), count.copy(), be.counters())
+            finally:
+                be.release()
+        except Exception as e:  # noqa: BLE001 (reported by the main thread)
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(i, *job)) for i, job in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (name, da, extra) in enumerate(jobs):
+        sc, per_it = per_iteration[name, da]
+        m = Model(per_it)
+        for k in range(30):
+            m.add(k)
+        color, count, counters = results[i]
+        assert np.array_equal(count, m.count) and np.array_equal(color.view(np.uint32), m.color.view(np.uint32)), name
+        assert counters == m.totals, name
