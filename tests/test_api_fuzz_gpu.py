@@ -245,9 +245,9 @@ def test_random_call_sequences_super_sampling(seed, per_iteration):
         be.release()
 
 
-def test_two_contexts_driven_from_two_threads(per_iteration):
-    """Contexts share nothing a caller can see: two of them - different scenes, arithmetics and kernels - driven at the same time
-    from two host threads (ctypes releases the interpreter lock inside the calls) produce what each produces alone."""
+def test_contexts_driven_from_concurrent_threads(per_iteration):
+    """Contexts share nothing a caller can see: four of them - different scenes, arithmetics and kernels - driven at the same time
+    from four host threads (ctypes releases the interpreter lock inside the calls) produce what each produces alone."""
     import threading
     jobs = [("cornell", True, 0), ("fuzz3_l1", False, 0), ("fuzz5h_l1", True, 0), ("cornell", False, backend.FLAG_MEGAKERNEL)]
     results, errors = {}, []
