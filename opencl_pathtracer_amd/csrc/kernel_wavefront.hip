@@ -36,6 +36,11 @@
 //    takes its next step changes, never WHICH tests it makes or what they see (see leaf_pass for the one place
 //    where tests of one ray run side by side).  Results are bit-identical to the one-path-per-lane kernel
 //    (kernels.hip) and to the CPU checker.
+//  * The one thing a leaf pass cannot express is a NaN distance (the reference accepts it and then keeps the LAST triangle
+//    that passes, not the nearest): a path whose ray is not a number is GIVEN UP where path logic sets the ray up - a marked
+//    radiance goes to its staging slot - and redo_poisoned_kernel, queued behind every staged launch, traces it again with
+//    the reference's literal loops (ptmi_literal_path.hpp).  Scenes whose RECORDS yield NaN distances never get here
+//    (ptmi_api.cpp: scene_needs_literal_kernel).
 //
 // Exit: a lane dies when it has seen every queue empty; a wave leaves the outer loop when no lane is alive
 // (every path is bounded by the ray depth, every traversal by the finite tree, and a pass or trip only runs
