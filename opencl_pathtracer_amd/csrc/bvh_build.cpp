@@ -97,7 +97,8 @@ struct Builder {
     ptmi_bounding_box l2r_box[3][kBins], r2l_box[3][kBins];
     int l2r_count[3][kBins], r2l_count[3][kBins];
     float k1[3] = { 0, 0, 0 };
-    bool failed = false;  // a centroid fell outside its node's bins
+    bool failed = false;    // a centroid fell outside its node's bins, or a split left a side empty
+    uint32_t capacity = 0;  // nodes the caller's array holds: 2n - 1
 
     void make_node(uint32_t idx, uint32_t start, uint32_t count, const ptmi_bounding_box& tri_box,
                    const ptmi_bounding_box& cen_box)
@@ -211,6 +212,10 @@ struct Builder {
         const uint32_t son2_count = (uint32_t)r2l_count[best_axis][best_index + 1];
         const ptmi_bounding_box son2_box = r2l_box[best_axis][best_index + 1];
 
+        // A split always leaves triangles on both sides when the costs are numbers, and the tree then has at most 2n - 1 nodes -
+        // what the caller allocated (BVH.cpp:20).  With boxes whose extents overflow it need not: refuse instead of writing past
+        // the array (the reference would).
+        if (l2r_count[best_axis][best_index] <= 0 || son2_count == 0 || (uint64_t)size + 2 > capacity) { failed = true; return idx + 1; }
         depth++;
         size += 2;
 
@@ -219,6 +224,7 @@ struct Builder {
         make_node(son1, (uint32_t)first, (uint32_t)l2r_count[best_axis][best_index], l2r_box[best_axis][best_index],
                   left_cen);
         const uint32_t son2 = build(son1);
+        if (failed || son2 >= capacity) { failed = true; depth--; return idx + 1; }
         nodes[idx].son2_id = son2;
         make_node(son2, son2_start, son2_count, son2_box, right_cen);
         const uint32_t next = build(son2);
@@ -260,6 +266,7 @@ extern "C" int ptmi_bvh_create(ptmi_triangle* triangulation, uint32_t n, ptmi_no
     Builder& b = holder[0];
     b.tris = triangulation;
     b.nodes = bvh;
+    b.capacity = 2u * n - 1u;
     b.make_node(0, 0, n, full_tri, full_cen);
     b.size = 1;
     b.build(0);

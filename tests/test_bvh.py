@@ -160,6 +160,32 @@ def test_boxes_that_are_not_numbers_are_an_error_not_a_fault(value, built):
             assert e.value.code == -5
 
 
+def test_builder_under_sanitizers(tmp_path):
+    """csrc/bvh_build.cpp compiled with g++ -fsanitize=address,undefined and run on the fuzzed scenes (valid, hostile, corrupted
+    records) and on boxes that are not numbers: no out-of-bounds access, no undefined behaviour.  (It found the node array
+    overrun of a split that leaves one side empty - boxes whose extents overflow - which is an error code now.)"""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not installed")
+    asan = subprocess.run([gxx, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan = subprocess.run([gxx, "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan) and os.path.isabs(ubsan) and os.path.exists(ubsan)):
+        pytest.skip("libasan / libubsan not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "stub.cpp"
+    stub.write_text('#include <string>\nnamespace ptmi_internal { void set_global_error(const std::string&) {} }\n')
+    so = tmp_path / "libbvh_asan.so"
+    r = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                        "-fno-sanitize-recover=undefined", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "opencl_pathtracer_amd", "csrc"),
+                        os.path.join(root, "opencl_pathtracer_amd", "csrc", "bvh_build.cpp"), str(stub), "-o", str(so)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = {**os.environ, "LD_PRELOAD": asan + ":" + ubsan, "ASAN_OPTIONS": "detect_leaks=0"}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sanitize", "bvh_builder_asan.py"), str(so)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
 def test_empty_triangulation_is_an_error(built):
     sc = scenes.cornell_box(8, 8)
     sc.triangulation = np.zeros(0, S.Triangle)
