@@ -13,7 +13,7 @@ OBJDIR     := $(LIBDIR)/obj
 # The integrator's device code is compiled once per arithmetic mode (ptmi_device.hpp): strict, and `_da` = the
 # reference's default OpenCL arithmetic (PTMI_FLAG_DEFAULT_ARITHMETIC).  Object files: `make -j` builds them side by side.
 LIB_OBJS   := $(OBJDIR)/kernels.o $(OBJDIR)/kernel_wavefront.o $(OBJDIR)/kernels_da.o $(OBJDIR)/kernel_wavefront_da.o \
-              $(OBJDIR)/display.o $(OBJDIR)/ptmi_api.o $(OBJDIR)/bvh_build.o
+              $(OBJDIR)/display.o $(OBJDIR)/ptmi_api.o $(OBJDIR)/scene_layout.o $(OBJDIR)/bvh_build.o
 
 .PHONY: all lib shim oracle ref clean resources
 all: lib shim oracle

@@ -288,6 +288,11 @@ void ptmi_device_share(uint32_t first_iteration, uint32_t n_iterations, uint32_t
  * binned-SAH build, bit-compatible with the reference (same node order, same
  * in-place reordering of `triangulation`).  `bvh` must hold 2*n-1 nodes.
  * Host only; needs no device. */
+/* Host-only (no device, no context): would ptmi_initialize_memory accept `scene` on a context set up with `config`?  The same
+ * checks - every index the kernel will follow, texture extents, texture coordinates, the tree's structure and depth - and the
+ * same error codes, with the message in ptmi_last_error(NULL).  For importers and asset pipelines on machines without a GPU. */
+int ptmi_validate_scene(const ptmi_config* config, const ptmi_scene* scene);
+
 int ptmi_bvh_create(ptmi_triangle* triangulation, uint32_t triangulation_size, ptmi_node* bvh,
                     uint32_t* bvh_size, uint32_t* bvh_max_depth);
 

@@ -6,6 +6,6 @@
 `scene_cache` - the reference's scene-cache files (sizes.pth / pointers.pth / textureData.pth)
 """
 from . import structs, scenes, backend, scene_cache, output, obj_import  # noqa: F401
-from .backend import Backend, PtmiError, bvh_create, render_scene  # noqa: F401
+from .backend import Backend, PtmiError, bvh_create, render_scene, validate_scene  # noqa: F401
 
-__all__ = ["structs", "scenes", "backend", "scene_cache", "output", "obj_import", "Backend", "PtmiError", "bvh_create", "render_scene"]
+__all__ = ["structs", "scenes", "backend", "scene_cache", "output", "obj_import", "Backend", "PtmiError", "bvh_create", "render_scene", "validate_scene"]

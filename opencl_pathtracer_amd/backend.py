@@ -96,7 +96,7 @@ FLAG_SOURCE_SEED = 32  # non-parity mode: seed 1 (as the source text reads) wher
 
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
-               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats", "ptmi_get_invariant_checks", "ptmi_literal_kernel_reason",
+               "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats", "ptmi_get_invariant_checks", "ptmi_literal_kernel_reason", "ptmi_validate_scene",
                "ptmi_kernel_time",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
@@ -136,6 +136,7 @@ def load_library():
     lib.ptmi_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.ptmi_get_scheduler_stats.argtypes = [vp, C.POINTER(SchedulerStats)]
     lib.ptmi_get_invariant_checks.argtypes = [vp, C.POINTER(InvariantChecks)]
+    lib.ptmi_validate_scene.argtypes = [C.POINTER(Config), C.POINTER(SceneDesc)]
     lib.ptmi_literal_kernel_reason.argtypes = [vp]
     lib.ptmi_literal_kernel_reason.restype = C.c_char_p
     lib.ptmi_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
@@ -190,6 +191,39 @@ def bvh_create(scene):
     return scene
 
 
+def scene_desc(scene):
+    """(ptmi_scene struct pointing into contiguous copies of the scene's arrays, those arrays - keep them alive while it is used)"""
+    arrays = dict(bvh=np.ascontiguousarray(scene.bvh), tri=np.ascontiguousarray(scene.triangulation),
+                  lights=np.ascontiguousarray(scene.lights), mats=np.ascontiguousarray(scene.materiaux),
+                  tex=np.ascontiguousarray(scene.textures), texels=np.ascontiguousarray(scene.texturesData),
+                  sky=np.ascontiguousarray(scene.sky))
+    assert arrays["bvh"].dtype == S.Node and arrays["tri"].dtype == S.Triangle
+    d = SceneDesc()
+    d.struct_size = C.sizeof(SceneDesc)
+    d.bvh, d.bvh_size = _ptr(arrays["bvh"]), len(arrays["bvh"])
+    d.triangulation, d.triangulation_size = _ptr(arrays["tri"]), len(arrays["tri"])
+    d.lights, d.lights_size = _ptr(arrays["lights"]), len(arrays["lights"])
+    d.materiaux, d.materiaux_size = _ptr(arrays["mats"]), len(arrays["mats"])
+    d.textures, d.textures_size = _ptr(arrays["tex"]), len(arrays["tex"])
+    d.textures_data, d.textures_data_size = _ptr(arrays["texels"]), len(arrays["texels"])
+    d.sky = arrays["sky"].ctypes.data_as(C.c_void_p)
+    d.camera_position, d.camera_direction = _f4(scene.cameraPosition), _f4(scene.cameraDirection)
+    d.camera_right, d.camera_up = _f4(scene.cameraRight), _f4(scene.cameraUp)
+    return d, arrays
+
+
+def validate_scene(scene, image_width, image_height, ray_max_depth, sampler=S.JITTERED, super_sampling=False, flags=0):
+    """ptmi_validate_scene: would initialize_memory accept this scene on such a context?  Host-only (no GPU needed).  Raises
+    PtmiError with the library's message if not."""
+    lib = load_library()
+    cfg = Config(C.sizeof(Config), 0, image_width, image_height, ray_max_depth, scene.lightsSize, sampler, 1 if super_sampling else 0, flags)
+    d, keep = scene_desc(scene)
+    rc = lib.ptmi_validate_scene(C.byref(cfg), C.byref(d))
+    del keep
+    if rc:
+        raise PtmiError(rc, lib.ptmi_last_error(None).decode())
+
+
 class Backend:
     """One render context = the file-scope OpenCL objects of PathTracer_OpenCL.cpp:19-47."""
 
@@ -227,23 +261,9 @@ class Backend:
 
     # -- OpenCL_InitializeMemory(globalVars), OpenCL.cpp:149-198 --------------------------
     def initialize_memory(self, scene):
-        arrays = dict(bvh=np.ascontiguousarray(scene.bvh), tri=np.ascontiguousarray(scene.triangulation),
-                      lights=np.ascontiguousarray(scene.lights), mats=np.ascontiguousarray(scene.materiaux),
-                      tex=np.ascontiguousarray(scene.textures), texels=np.ascontiguousarray(scene.texturesData),
-                      sky=np.ascontiguousarray(scene.sky))
-        assert arrays["bvh"].dtype == S.Node and arrays["tri"].dtype == S.Triangle
-        d = SceneDesc()
-        d.struct_size = C.sizeof(SceneDesc)
-        d.bvh, d.bvh_size = _ptr(arrays["bvh"]), len(arrays["bvh"])
-        d.triangulation, d.triangulation_size = _ptr(arrays["tri"]), len(arrays["tri"])
-        d.lights, d.lights_size = _ptr(arrays["lights"]), len(arrays["lights"])
-        d.materiaux, d.materiaux_size = _ptr(arrays["mats"]), len(arrays["mats"])
-        d.textures, d.textures_size = _ptr(arrays["tex"]), len(arrays["tex"])
-        d.textures_data, d.textures_data_size = _ptr(arrays["texels"]), len(arrays["texels"])
-        d.sky = arrays["sky"].ctypes.data_as(C.c_void_p)
-        d.camera_position, d.camera_direction = _f4(scene.cameraPosition), _f4(scene.cameraDirection)
-        d.camera_right, d.camera_up = _f4(scene.cameraRight), _f4(scene.cameraUp)
+        d, keep = scene_desc(scene)
         self._check(self._lib.ptmi_initialize_memory(self._ctx, C.byref(d)))
+        del keep
         return self
 
     # -- one launch of the loop body of OpenCL_RunKernel, generalised to a range ----------
