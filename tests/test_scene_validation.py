@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "sanitize"))
 import scene_validation as V  # noqa: E402
 
+pytestmark = pytest.mark.filterwarnings("ignore::RuntimeWarning")  # (the hostile scenes divide 0 by 0 on purpose, as the importer would)
 MUST_FAIL = {"son_out_of_range", "son_cycle", "leaf_range", "leaf_count_huge", "cut_axis", "material_index", "texture_id", "sky_texture",
              "uv_huge", "uv_nan", "lights_mismatch", "texture_zero_size"}
 
