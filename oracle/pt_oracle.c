@@ -426,13 +426,30 @@ static int bbox_intersects(const ptmi_bounding_box* bb, ray_t* r, float squared_
 /* Textures, h:430-459; sky, cl:438-512                                       */
 /* ------------------------------------------------------------------------- */
 
+/* float -> integer as the GPU converts (v_cvt_i32_f32 / v_cvt_u32_f32: NaN gives 0, out-of-range values saturate): what the
+ * compiled reference and the integrator do where C leaves the conversion undefined (a hit whose barycentrics are NaN reaches
+ * the texture lookup with NaN coordinates: tests/sanitize/oracle_asan.py runs this file under -fsanitize=float-cast-overflow) */
+static inline int32_t gpu_f2i(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+static inline uint32_t gpu_f2u(float x)
+{
+    if (!(x > 0.0f)) return 0u; /* NaN, zero, negative */
+    if (x >= 4294967296.0f) return UINT32_MAX;
+    return (uint32_t)x;
+}
+
 static f4 texture_pixel(const ptmi_texture* tex, const ptmi_uchar4* data, float u, float v)
 {
     uint32_t x, y;
-    u = u - (float)((int)u) + (float)(u < 0 ? 1 : 0);
-    v = v - (float)((int)v) + (float)(v < 0 ? 1 : 0);
-    x = (uint32_t)(u * (float)(tex->width - 1u));
-    y = (uint32_t)(v * (float)(tex->height - 1u));
+    u = u - (float)gpu_f2i(u) + (float)(u < 0 ? 1 : 0);
+    v = v - (float)gpu_f2i(v) + (float)(v < 0 ? 1 : 0);
+    x = gpu_f2u(u * (float)(tex->width - 1u));
+    y = gpu_f2u(v * (float)(tex->height - 1u));
     {
         const uint32_t index = tex->offset + y * tex->width + x;
         const ptmi_uchar4 p = data[index];

@@ -182,3 +182,32 @@ def test_oracle_equals_both_reference_builds_on_fuzzed_scenes(built):
         for da, key in ((False, name), (True, name + "_default")):
             color, count, (dep, bbx, tri), _ = O.oracle_render(sc, w, h, d, cases.FEATURE_SPP, default_arithmetic=da)
             assert cases.result_digest(color, count, dep, bbx, tri) == str(fx[key]), key
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """oracle/pt_oracle.c, both arithmetics, compiled with gcc -fsanitize=address,undefined,float-cast-overflow and run on the
+    committed fuzz scenes: the checker itself reads nothing outside the scene's arrays and converts no NaN to an integer the way
+    C leaves undefined (it restates the GPU's conversions: v_cvt gives 0 for NaN and saturates)."""
+    import shutil
+    import subprocess
+    import sys
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not installed")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan = subprocess.run([gcc, "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan) and os.path.isabs(ubsan) and os.path.exists(ubsan)):
+        pytest.skip("libasan / libubsan not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libs = []
+    for da in (0, 1):
+        so = tmp_path / f"libpt_oracle_{da}_asan.so"
+        r = subprocess.run([gcc, "-std=c11", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fexcess-precision=standard", "-mfma",
+                            "-pthread", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                            f"-DPTO_DEFAULT_ARITHMETIC={da}", "-I" + os.path.join(root, "include"), "-shared",
+                            os.path.join(root, "oracle", "pt_oracle.c"), "-o", str(so), "-lm"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        libs.append(str(so))
+    env = {**os.environ, "LD_PRELOAD": asan + ":" + ubsan, "ASAN_OPTIONS": "detect_leaks=0"}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "sanitize", "oracle_asan.py"), *libs], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
