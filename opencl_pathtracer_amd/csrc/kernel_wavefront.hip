@@ -40,7 +40,7 @@
 //    that passes, not the nearest): a path whose ray is not a number is GIVEN UP where path logic sets the ray up - a marked
 //    radiance goes to its staging slot - and redo_poisoned_kernel, queued behind every staged launch, traces it again with
 //    the reference's literal loops (ptmi_literal_path.hpp).  Scenes whose RECORDS yield NaN distances never get here
-//    (ptmi_api.cpp: scene_needs_literal_kernel).
+//    (scene_layout.cpp: scene_needs_literal_kernel).
 //
 // Exit: a lane dies when it has seen every queue empty; a wave leaves the outer loop when no lane is alive
 // (every path is bounded by the ray depth, every traversal by the finite tree, and a pass or trip only runs
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                 // a hit on a fake plane 1e30 away overflows - makes every triangle test compute a NaN distance, and the
                 // reference ACCEPTS those (its rejections are comparisons, cl:533-567): from then on nothing is "too far" and
                 // the LAST triangle that passes wins - not a minimum over ordered keys, which is what a leaf pass keeps.
-                // With finite rays from origins below 2^40 and the records the upload admits (ptmi_api.cpp:
+                // With finite rays from origins below 2^40 and the records the upload admits (scene_layout.cpp:
                 // scene_needs_literal_kernel) a distance is always a number.  So such a path is GIVEN UP here: it restarts
                 // its counters, takes a marked NaN for its radiance and its query ends before it starts - as a miss, so the
                 // next pass finishes the path the ordinary way (one segment, no hit) - and redo_poisoned_kernel, behind the

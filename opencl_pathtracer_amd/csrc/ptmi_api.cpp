@@ -99,7 +99,7 @@ struct ptmi_ctx {
     uint32_t stack_levels = PTMI_BVH_MAX_DEPTH;
     uint32_t iterations_per_launch = kMaxIterationsPerLaunch;
     // Why the uploaded scene is rendered by the one-path-per-lane kernel although the context did not ask for it (empty: it is
-    // not).  See scene_needs_literal_kernel().
+    // not).  See scene_needs_literal_kernel() in scene_layout.cpp.
     std::string literal_kernel_reason;
 
     // RCCL communicators, one per device of the context (single process, ncclCommInitAll): the sum of the devices' partial
