@@ -2,7 +2,8 @@
 """Many samples on many fuzzed scenes: the integrator against the reference kernel run beside it, bit for bit.  (GPU box; needs
 oracle/_ref.)  What a 24-spp test cannot see - an event once in a million paths, like the refraction that makes a ray NaN - shows
 in millions of paths per scene.
-usage: tools/fuzz_soak.py [FIRST_SEED [N_SEEDS [SPP]]]  > profiles/r03_fuzz_soak.json   (progress on stderr)"""
+usage: tools/fuzz_soak.py [FIRST_SEED [N_SEEDS [SPP]]]  > profiles/r03_fuzz_soak.json   (progress on stderr;
+SOAK_PARTIAL=file: the same JSON rewritten after every scene, for runs under a time limit)"""
 import json
 import os
 import sys
@@ -59,6 +60,9 @@ def main():
                                               "depths_ours": ours[2][0].tolist(), "depths_reference": ref[2][0].tolist()})
             out["scenes"].append(sc.name)
             print(f"{sc.name}: {len(out['mismatches'])} mismatches so far, {out['paths'] / 1e6:.0f} M paths, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+            if os.environ.get("SOAK_PARTIAL"):  # a run under a time limit still leaves its figures: rewritten after every scene
+                with open(os.environ["SOAK_PARTIAL"], "w") as f:
+                    json.dump({**out, "note": "partial: rewritten after every scene"}, f, indent=1)
     print(json.dumps(out, indent=1))
 
 
