@@ -107,6 +107,8 @@ def run(lib, seeds=range(0, 24)):
         for name in (f"fuzz{seed}_l1", f"fuzz{seed}hr_l3", "matmix" if seed % 4 == 0 else "cornell"):
             assert validate(with_tree(name)) == 0, name
             assert validate(with_tree(name), sampler=S.RANDOM) == 0, name
+            # boxes that do not bound, inverted, NaN / infinite faces, foreign split axes: structurally valid, so accepted
+            assert validate(scenes.corrupt_tree(with_tree(name), seed)) == 0, name + " (corrupted tree)"
             rs = np.random.RandomState(31 * seed + len(name))
             for kind in CORRUPTIONS:
                 sc = with_tree(name)
