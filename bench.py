@@ -52,10 +52,25 @@ L1_FILL_RATE_L2 = 258.2e9
 L1_FILL_RATE_MALL = 58.1e9
 
 
-def algorithmic_bytes(c, n_pixels, n_flush):
-    """32 B per box test, 48 B per triangle test, 96 B per surface hit, 40 B per pixel per
-    accumulator flush (texel reads: none in the BASELINE workloads that are timed here)."""
-    return 32 * c["box_tests"] + 48 * c["triangle_tests"] + 96 * c["surface_hits"] + 40 * n_pixels * n_flush
+def algorithmic_bytes(c, n_pixels, n_flush, textured_hits=0):
+    """32 B per box test, 48 B per triangle test, 96 B per surface hit (+ 24 B of uv and 4 B of texel per hit on
+    a textured material), 40 B per pixel per accumulator flush."""
+    return 32 * c["box_tests"] + 48 * c["triangle_tests"] + 96 * c["surface_hits"] + 28 * textured_hits + 40 * n_pixels * n_flush
+
+
+def textured_hit_fraction(pt, scene, W, H, D, device, flags):
+    """Surface hits on a material with a file texture / all surface hits, from ONE iteration of the statistics build of the
+    kernel (ptmi_scheduler_stats.textured_hits: the production instantiation does not count them)."""
+    if len(scene.textures) == 0 or not (scene.materiaux["isSimpleColor"] == 0).any():
+        return 0.0
+    from opencl_pathtracer_amd.backend import FLAG_SCHEDULER_STATS
+    be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=device, flags=flags | FLAG_SCHEDULER_STATS)
+    be.initialize_memory(scene)
+    be.render(0, 1)
+    be.synchronize()
+    c, s = be.counters(), be.scheduler_stats()
+    be.release()
+    return s["textured_hits"] / max(c["surface_hits"], 1)
 
 
 def main():
@@ -197,14 +212,17 @@ def main():
         spp_done = (args.warmup + args.steps) * B * (1 if strong else world)
         assert np.isfinite(color).all() and float(count.min()) == float(spp_done) == float(count.max()), \
             f"sample count {count.min()}..{count.max()} != {spp_done}"
-        b_alg = algorithmic_bytes(delta, n_pix, launches)
+        tex_frac = textured_hit_fraction(pt, scene, W, H, D, local_rank, flags) if args.kernel == "wavefront" else 0.0
+        n_texel = tex_frac * delta["surface_hits"]
+        b_alg = algorithmic_bytes(delta, n_pix, launches, n_texel)
         avg_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = b_alg / max(launches, 1) / avg_launch_s / 1e9
         records_per_launch = (delta["box_tests"] / 2 + delta["triangle_tests"]) / max(launches, 1)
         model = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
                  "algorithmic_bytes_per_launch": b_alg / max(launches, 1),
-                 "note": "SURVEY 8d ALGORITHMIC bytes (32 B per box test, 48 B per triangle test, 96 B per surface hit, 40 B per "
-                         "pixel flush) / launch time: what the traversal must read, nearly all of it served by the L1s / L2s / "
+                 "textured_hits_per_surface_hit": tex_frac, "texel_lookups_per_launch": n_texel / max(launches, 1),
+                 "note": "SURVEY 8d ALGORITHMIC bytes (32 B per box test, 48 B per triangle test, 96 B per surface hit, 24 B of uv + "
+                         "4 B of texel per hit on a textured material, 40 B per pixel flush) / launch time: what the traversal must read, nearly all of it served by the L1s / L2s / "
                          "Infinity Cache (hbm_measured is what reaches memory) - a model of the work, NOT a ceiling of this kernel"}
         roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "kernel": "render_wavefront_kernel" if args.kernel == "wavefront" else "render_kernel",
@@ -289,7 +307,10 @@ def workload_name(scene):
             "tris4m": "larger variant of configs[2]: 4M random triangles, 427 MB of records (> the 256 MiB Infinity Cache; still not "
                       "HBM-bound: measured memory-side traffic is ~0.2 % of the HBM peak)",
             "cornell": "BASELINE configs[0]/[1]: Cornell box (point light under a lamp quad)",
-            "matmix": "BASELINE configs[4] stand-in: textured multi-material scene (no Maya assets exist)"}.get(scene, scene)
+            "mayalike": "BASELINE configs[4] stand-in (SURVEY 8d Config 5; no Maya SDK or asset exists): a modelled outdoor set as "
+                        "PathTracerMayaImporter would hand it over - tessellated terrain, spheres, torus, pond, walls; Lambert / Phong "
+                        "materials + glass, water, metal; four 1024x1024 RGBA file textures, 6 x 512x512 cube-map sky",
+            "matmix": "toy material mix (every kernel branch in 1,174 triangles; NOT a BASELINE workload)"}.get(scene, scene)
 
 
 def kernel_source_digest():
@@ -512,11 +533,15 @@ def cpu_baseline(scene, W, H, D, rows, n_iter, default_arithmetic=False):
     import oracle_ffi as O
     cores = host_cores()
     if rows <= 0 or n_iter <= 0:
-        # a short probe gives this scene's rate; then aim at ~20 s of CPU work (10-30 s), whole images first
-        probe_rows = max(cores, min(H, 4 * cores))
+        # a short probe gives this scene's rate; then aim at ~20 s of CPU work (10-30 s), whole images first.  Three bands
+        # (top, middle, bottom of the image): the first rows alone may be all sky, whose paths are the cheapest there are
+        band = max(cores, min(H // 3, 2 * cores))
         t0 = time.perf_counter()
-        _, _, _, tot = oracle_rows(O, scene, W, H, D, probe_rows, cores, 1, default_arithmetic)
-        rate = tot["paths"] / max(time.perf_counter() - t0, 1e-6)
+        probed = 0
+        for row0 in (0, (H - band) // 2, H - band):
+            _, _, _, tot = oracle_rows(O, scene, W, H, D, band, cores, 1, default_arithmetic, first_row=row0)
+            probed += tot["paths"]
+        rate = probed / max(time.perf_counter() - t0, 1e-6)
         target_paths = 20.0 * rate
         if n_iter <= 0:
             n_iter = max(1, min(64, int(target_paths / (W * H) + 0.5)))
@@ -554,10 +579,9 @@ def host_cores():
     return n
 
 
-def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1, default_arithmetic=False):
-    """Render iterations 0..n_iter-1 for the first `rows` rows by running the oracle on a W x rows 'image' whose
-    camera rays equal those of rows 0..rows-1 of the full image: seed and jitter depend on (x, y, W, H),
-    so the full-size H is kept and only the row loop is cut short."""
+def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1, default_arithmetic=False, first_row=0):
+    """Render iterations 0..n_iter-1 of rows first_row..first_row+rows-1 of the full image: seed and jitter depend on
+    (x, y, W, H), so the full-size W and H are kept and only the row loop is cut short."""
     import ctypes as C
     import numpy as np
     lib = O.oracle(default_arithmetic)
@@ -572,7 +596,7 @@ def oracle_rows(O, scene, W, H, D, rows, threads, n_iter=1, default_arithmetic=F
     lib.pto_render_rows.argtypes = [C.POINTER(O.PtoScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(O.PtoBuffers), C.c_int, C.POINTER(O.PtoTotals)]
     lib.pto_render_rows.restype = None
-    lib.pto_render_rows(C.byref(osc.c), 0, n_iter, 0, rows, C.byref(buf), threads, C.byref(tot))
+    lib.pto_render_rows(C.byref(osc.c), 0, n_iter, first_row, first_row + rows, C.byref(buf), threads, C.byref(tot))
     return color, count, (dep, bbx, tri), tot.as_dict()
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 3 /* 3: PTMI_FLAG_DEFAULT_ARITHMETIC, ptmi_scheduler_stats::leaf_item_violations */
+#define PTMI_ABI_VERSION 4 /* 3: PTMI_FLAG_DEFAULT_ARITHMETIC, ptmi_scheduler_stats::leaf_item_violations; 4: ::textured_hits */
 #define PTMI_MAX_DEVICES 16       /* devices that can share one render */
 #define PTMI_MAX_SNAPSHOT_SLOTS 65 /* ptmi_snapshot ring: slots 0..63 are the caller's, the last one the library's own */
 
@@ -64,11 +64,14 @@ typedef struct ptmi_config {
     /* Multi-GPU render (the reference drives devices[0] only, OpenCL.cpp:363-366): n_devices > 1 replicates the scene on
      * devices[0..n_devices) and spreads the iteration ids of every ptmi_render call over them (device k takes the ids
      * congruent to k modulo n_devices: the same id set as a single-device render, so the same samples); devices[0] is
-     * the one the partial accumulators are summed on: ptmi_read_image / ptmi_read_display by an ncclReduce over xGMI
-     * (librccl, loaded at run time; environment PTMI_REDUCE=peer forces the fallback), ptmi_read_snapshot - the per-image
-     * loop, where one device's share changes per image - by one peer copy of that share + one add kernel in device order
-     * (also the fallback where RCCL is absent or refuses the device list).  n_devices 0 or 1 = single device `device`.
-     * A device may be listed more than once (used by the tests on a one-GPU box; RCCL refuses that, the fallback runs). */
+     * the one the partial accumulators are summed on, by peer copies over xGMI + one add kernel IN DEVICE ORDER (the float
+     * sums of an image are a function of the device list alone); the per-image loop (ptmi_read_snapshot), where one device's
+     * share changes per image, re-sends only that share.  Environment PTMI_REDUCE=rccl: the sum is an ncclReduce instead
+     * (librccl, loaded at run time, NCCL 2 API checked by ncclGetVersion) - opt-in: its order of additions for more than two
+     * devices is the collective algorithm's, so the last bits of an image depend on it, and any failure (library absent,
+     * device list refused, a run-time error) falls back to the peer path for the rest of the context's life.
+     * n_devices 0 or 1 = single device `device`.  A device may be listed more than once (used by the tests on a one-GPU box;
+     * RCCL refuses that, the peer path runs). */
     uint32_t n_devices;
     int32_t devices[PTMI_MAX_DEVICES];
 } ptmi_config;
@@ -137,6 +140,8 @@ typedef struct ptmi_scheduler_stats {
                                                 lane read them (an item read before its writer: must be 0; checked only while collecting) */
     uint64_t paths_retraced;                 /* paths a launch gave up because one of their rays was not a number, traced again by the
                                                 reference's literal loops (ptmi_literal_kernel_reason, below); counted ALWAYS, flag or not */
+    uint64_t textured_hits;                  /* surface hits whose material has a file texture (one texel fetch each at least: the
+                                                4 * N_texel term of the algorithmic-bytes model); counted only while collecting */
 } ptmi_scheduler_stats;
 
 /* The reference's device-side consistency checks: with -D LOG_INFO (OpenCL.cpp:310, globalVars.printLogInfos) its kernel
@@ -240,9 +245,12 @@ int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out);
  * The integrator reproduces that bit for bit.  Where the RAY is not a number (a refraction at |cos| = 1 + 1 ulp, cl:235) the
  * wavefront kernel gives the path up and re-traces it with the reference's literal loops (JITTERED / UNIFORM samplers).
  * Where the scene's RECORDS are the source - zero-area triangles, whose normal the importer computes as 0/0; non-finite or
- * astronomically large coordinates - the whole scene is rendered by the one-path-per-lane kernel (as with
- * PTMI_FLAG_MEGAKERNEL: same results, slower; PTMI_ERR_UNSUPPORTED with super_sampling): this call then returns why, else
- * NULL.  The string lives until the next ptmi_initialize_memory / ptmi_release. */
+ * astronomically large coordinates - this call returns why (else NULL), and the scene is rendered by an instantiation of the
+ * wavefront kernel that looks at every accepted triangle of a closest-hit query: only the paths that REACH such a record are
+ * given up and traced again by the literal loops (ptmi_scheduler_stats.paths_retraced), every other path runs as in a clean
+ * scene.  With the RANDOM sampler (nothing is staged there, so nothing can be traced again) such a scene is rendered by the
+ * one-path-per-lane kernel as a whole (as with PTMI_FLAG_MEGAKERNEL: same results, slower; PTMI_ERR_UNSUPPORTED with
+ * super_sampling).  The string lives until the next ptmi_initialize_memory / ptmi_release. */
 const char* ptmi_literal_kernel_reason(const ptmi_ctx* ctx);
 
 /* Device time of the integrator kernel launches issued by ptmi_render since the

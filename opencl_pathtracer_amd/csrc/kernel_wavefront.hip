@@ -54,6 +54,7 @@
 #include "ptmi_shading.hpp"
 #include "ptmi_literal_path.hpp"
 
+#include <atomic>
 #include <cstring>
 
 namespace PTMI_DEV_NS {
@@ -92,12 +93,15 @@ constexpr int kQueues = PTMI_WF_QUEUES;  // job queues (image stripes), one per 
 #define PTMI_WF_QUEUE_STRIDE 64
 #endif
 constexpr int kQueueStride = PTMI_WF_QUEUE_STRIDE;  // dwords between two queue counters (64 = one 256-byte block each)
+// word 1 of the job-counter block is the launch's "a path was given up" flag (redo_poisoned_kernel): free only while the
+// queue counters are at least two words apart
+static_assert(kQueueStride >= 2, "job_counter[1] is the given-up flag: queue counters must not be adjacent words");
 constexpr int kWaitDebtFixed = PTMI_WF_WAIT_DEBT;
 #ifndef PTMI_WF_HIT_WORDS
 // LDS words of the closest-hit record per lane.  8: hit point (4), s, t, triangle | front, found.  4: the ray parameter
 // instead of the point - path logic rebuilds the point from the ray it still holds with the very operations of the
 // triangle test, bit for bit - s, t, and one word triangle | front | found.  LDS per workgroup = (tree depth + 1 + words)
-// KB + 4 KB of leaf-pass keys and items (kLeafPassWords) = (depth + 9) KB with 4 words: trees up to depth 23 keep five
+// KB + 4 KB of leaf-pass keys and items (kLeafPassWords) = (depth + 9) KB with 4 words, plus the static counter block (8 * C_COUNT bytes): trees up to depth 22 keep five
 // workgroups per CU (160 KB); the 4M-triangle scene (depth 24: 33 KB) and the 16M one (depth 27) run four.
 // Measured on MI355X, same box, 1M triangles 1080p: 4 words 759-761, 8 words 751-753 Msamples/s.
 #define PTMI_WF_HIT_WORDS 4
@@ -182,7 +186,15 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
 // with the JITTERED sampler and without Russian roulette: the same operations for those renders, without the code - and
 // the registers - of the other material types, light types, samplers and of the light loop (1M triangles +4.9 %, Cornell
 // box +8.5 %).
-template <bool STATS, bool PRE, bool SS, bool PLAIN = false>
+// NANSAFE: for scenes whose RECORDS can make a triangle test compute a NaN distance (scene_layout.cpp:
+// scene_needs_literal_kernel - a zero-area triangle as the importer emits it, astronomical coordinates).  The reference accepts
+// such a test (its rejections are comparisons, FullKernel.cl:533-567) and from then on keeps the LAST triangle that passes,
+// which a minimum over ordered keys cannot express.  This instantiation looks at every ACCEPTED triangle of a closest-hit
+// query inside the leaf pass; a NaN distance there marks the owner's key, the owner gives its path up exactly like a path whose
+// ray is not a number, and redo_poisoned_kernel traces it again with the literal loops.  Everything else - and every path that
+// never reaches such a record - is the ordinary kernel.  (A shadow query needs nothing: it ends at the FIRST accepted triangle
+// in index order whatever the distances are, and its limit never changes.)  Clean scenes run the instantiations without it.
+template <bool STATS, bool PRE, bool SS, bool PLAIN = false, bool NANSAFE = false>
 __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN_WAVES_GENERAL) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc_arg, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t iteration_stride,
@@ -435,8 +447,12 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                               [&](const V4&, float ray_t, float s, float t, bool front, float nsd) {
                     // every lane that accepts is here at the same time: one LDS minimum for all of them, then each asks
                     // whether it is (so far) the one its owner keeps
+                    // (NANSAFE: an accepted NaN distance of a closest-hit query -> key 0, below every real key: a distance
+                    // under 1e-5 is never accepted, cl:543)
+                    const bool nan_hit = NANSAFE && !w_shadow && !(nsd == nsd);
                     const unsigned long long key = w_shadow ? ((unsigned long long)w_tri << 32)
-                                                            : (((unsigned long long)__float_as_uint(nsd) << 32) | (unsigned long long)(~w_tri));
+                                                   : nan_hit ? 0ull
+                                                   : (((unsigned long long)__float_as_uint(nsd) << 32) | (unsigned long long)(~w_tri));
                     atomicMin(owner_key, key);
                     if (!w_shadow && *owner_key == key) {  // the closest so far: its record is the one path logic shades from
                         uint32_t* const rec_out = &stack_mem[wave_first + owner];
@@ -450,6 +466,18 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
         }
         if (cnt != 0u) {
             const uint32_t won = (uint32_t)(key_mem[tid] >> 32);
+            if (NANSAFE && !shadow && won == 0u) {
+                // a triangle of this leaf was accepted with a NaN distance: the path is given up (as where path logic meets
+                // a ray that is not a number, below) - marked radiance, counters back to zero, the query ends as a miss -
+                // and redo_poisoned_kernel traces it again
+                const float m = __uint_as_float(kPoisonMarker);
+                radiance = v4(m, m, m, m);
+                transfer = v4(1, 1, 1, 1);
+                reflection = 0; p_bbx = 0; p_tri = 0;
+                hit_mem[kWordTri * kWfBlock] = 0;
+                cur = REF_NONE; tri_i = tri_end = 0; sp = stack_floor;
+                job_counter[1] = 1u;
+            } else
             if (!shadow) {
                 limit = __uint_as_float(won);
                 p_tri += cnt; tri_i += cnt;
@@ -735,6 +763,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                         check(gathered.x >= 0 && gathered.y >= 0 && gathered.z >= 0, C_CHK_RADIANCE);  // cl:951
                     }
                     if (do_scatter) {
+                        if (STATS && !PLAIN && !sf.mat.is_simple_color) atomicAdd(&block_counters[C_TEXTURED_HITS], 1ull);
                         r.d = cam_d;
                         V4 out;
                         V4 out_normal = v4(0, 0, 0, 0);
@@ -1097,18 +1126,8 @@ static int resident_blocks_of(Kernel kernel, uint32_t stack_levels)
     return per_cu * n_cu;
 }
 
-int PTMI_ARITH(wavefront_resident_blocks)(int device, uint32_t stack_levels)
-{
-    int before = 0;
-    (void)hipGetDevice(&before);
-    if (hipSetDevice(device) != hipSuccess) return 0;
-    const int n = resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, true>, stack_levels);
-    (void)hipSetDevice(before);
-    return n;
-}
-
 int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
-                            uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, int resident_blocks, uint32_t stack_levels,
+                            uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, uint32_t stack_levels,
                             bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err)
 {
     if (n_iterations == 0) return PTMI_OK;
@@ -1122,7 +1141,6 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
     hipError_t e = hipMemsetAsync(job_counter, 0, PTMI_DEV_NS::kQueues * PTMI_DEV_NS::kQueueStride * sizeof(uint32_t), (hipStream_t)stream);
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + PTMI_DEV_NS::kWfBlock - 1) / PTMI_DEV_NS::kWfBlock;
-        (void)resident_blocks;
         const dim3 b(PTMI_DEV_NS::kWfBlock);
         const size_t lds = wavefront_lds_bytes(stack_levels);
         const uint32_t lv = clamp_levels(stack_levels);
@@ -1137,32 +1155,44 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         warm.wide_records = sc.wide_records;
         warm.russian_roulette = sc.russian_roulette;
         warm.source_seed = sc.source_seed;
+        constexpr int kMaxCachedDevices = 64;
+        int device = 0;
+        const bool cached_device = hipGetDevice(&device) == hipSuccess && device >= 0 && device < kMaxCachedDevices;
         const bool plain = sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette &&
-                           sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats;
+                           sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats && !sc.nan_safe;
         warm.wait_debt = lv >= 16u ? 768u : (plain ? 320u : 512u);  // (the cheaper a path-logic pass, the sooner it pays)
-        // the persistent grid of the chosen instantiation (they differ in registers, hence in workgroups per CU); the caller's
-        // `resident_blocks` (of the plain-scene instantiation) only caps it
-#define PTMI_LAUNCH_WF_IMPL(S, P, A, L)                                                                                   \
+        // the persistent grid of the chosen instantiation on the CURRENT device (instantiations differ in registers, devices in
+        // CUs and partition mode, hence in workgroups held at once): asked once per (instantiation, device, stack levels);
+        // host threads that drive contexts of their own may race for an entry, and then write the same value
+#define PTMI_LAUNCH_WF_IMPL(S, P, A, L, N)                                                                                \
     do {                                                                                                                  \
-        auto kernel = PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L>;                                                    \
-        static int resident[PTMI_BVH_MAX_DEPTH + 1] = {};                                                                  \
-        if (resident[lv] == 0) resident[lv] = resident_blocks_of(kernel, lv);                                             \
+        auto kernel = PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L, N>;                                                 \
+        static std::atomic<int> resident_cache[kMaxCachedDevices][PTMI_BVH_MAX_DEPTH + 1];                                 \
+        int resident = cached_device ? resident_cache[device][lv].load(std::memory_order_relaxed) : 0;                     \
+        if (resident == 0) {                                                                                               \
+            resident = resident_blocks_of(kernel, lv);                                                                     \
+            if (cached_device) resident_cache[device][lv].store(resident, std::memory_order_relaxed);                      \
+        }                                                                                                                  \
         uint32_t nb = blocks;                                                                                             \
-        if (resident[lv] > 0 && nb > (uint32_t)resident[lv]) nb = (uint32_t)resident[lv];                                 \
+        if (resident > 0 && nb > (uint32_t)resident) nb = (uint32_t)resident;                                             \
         hipLaunchKernelGGL(kernel, dim3(nb), b, lds, st, scene_in_device_memory, warm, first_iteration, n_iterations,      \
                            iteration_stride, n_jobs, job_counter, lv, stage, stage_stats);                                \
     } while (0)
-#define PTMI_LAUNCH_WF(S, P, A)                                                                                       \
-    PTMI_LAUNCH_WF_IMPL(S, P, A, false)
-        // instantiations: the common case (no statistics, no adaptive sampling) pays for neither
+#define PTMI_LAUNCH_WF(S, P, A, N)                                                                                    \
+    PTMI_LAUNCH_WF_IMPL(S, P, A, false, N)
+        // instantiations: the common case (no statistics, no adaptive sampling, records that cannot yield NaN distances) pays
+        // for none of them; the statistics and SUPER_SAMPLING builds always carry the NaN check (two instructions per
+        // accepted triangle)
         if (sc.super_sampling) {
-            if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, true); else PTMI_LAUNCH_WF(true, false, true);
+            if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, true, true); else PTMI_LAUNCH_WF(true, false, true, true);
         } else if (scheduler_stats) {
-            if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false); else PTMI_LAUNCH_WF(true, false, false);
+            if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false, true); else PTMI_LAUNCH_WF(true, false, false, true);
+        } else if (sc.nan_safe) {
+            if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, true); else PTMI_LAUNCH_WF(false, false, false, true);
         } else {
-            if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true);  // the common case, BASELINE's untextured scenes among them
-            else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false);
-            else PTMI_LAUNCH_WF(false, false, false);
+            if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true, false);  // the common case, BASELINE's untextured scenes among them
+            else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, false);
+            else PTMI_LAUNCH_WF(false, false, false, false);
         }
 #undef PTMI_LAUNCH_WF
 #undef PTMI_LAUNCH_WF_IMPL

@@ -63,7 +63,6 @@ struct DeviceState {
     hipEvent_t stage_free[2] = {nullptr, nullptr};  // recorded on the main stream behind the accumulation
     bool stage_busy[2] = {false, false};
     uint32_t launches_issued = 0;
-    int resident_blocks = 0;
     DScene ds{};
     DScene* d_scene = nullptr;  // device copy of ds (what the wavefront kernel's path logic reads)
     // ptmi_snapshot ring: float[5*W*H] per slot (colour, then count), allocated on first use
@@ -126,8 +125,17 @@ namespace {
 bool default_arithmetic(const ptmi_ctx* ctx) { return (ctx->cfg.flags & PTMI_FLAG_DEFAULT_ARITHMETIC) != 0; }
 #define KERNELS_OF(ctx, name) (default_arithmetic(ctx) ? name##_da : name)
 
-// one path per lane (kernels.hip) instead of the wavefront kernel: asked for, or needed by the scene
-bool one_path_per_lane(const ptmi_ctx* ctx) { return (ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0 || !ctx->literal_kernel_reason.empty(); }
+// one path per lane (kernels.hip) instead of the wavefront kernel: asked for, or needed by the scene - records that can yield
+// NaN distances (literal_kernel_reason) rendered with the RANDOM sampler, whose samples are not staged, so that a path the
+// wavefront kernel gives up could not be traced again; with the other samplers such a scene runs the wavefront kernel's
+// NANSAFE instantiation (PTMI_LITERAL_KERNEL=1: the one-path-per-lane kernel as a whole, as before round 4, for A/B runs)
+bool one_path_per_lane(const ptmi_ctx* ctx)
+{
+    if ((ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) != 0) return true;
+    if (ctx->literal_kernel_reason.empty()) return false;
+    const char* force = std::getenv("PTMI_LITERAL_KERNEL");
+    return ctx->cfg.sampler == PTMI_SAMPLER_RANDOM || (force && force[0] == '1');
+}
 
 int fail(ptmi_ctx* ctx, int code, const std::string& msg)
 {
@@ -303,9 +311,9 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     std::memcpy(ds.cam_dir, &sc->camera_direction, 16);
     std::memcpy(ds.cam_right, &sc->camera_right, 16);
     std::memcpy(ds.cam_up, &sc->camera_up, 16);
-    d.resident_blocks = KERNELS_OF(ctx, wavefront_resident_blocks)(d.device, ctx->stack_levels);
     ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
     ds.plain_shading = lay.plain_shading ? 1u : 0u;
+    ds.nan_safe = lay.literal_kernel_reason.empty() ? 0u : 1u;
     ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
     ds.root_ref = lay.root_ref;
     ds.width = ctx->cfg.image_width;
@@ -476,7 +484,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 if (may_overlap && d.stage_busy[set]) e = hipStreamWaitEvent(ls, d.stage_free[set], 0);
                 if (e != hipSuccess) break;
                 rc = KERNELS_OF(ctx, launch_render_wavefront)(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter + set * 8 * 1024,
-                                             d.resident_blocks, ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, stage,
+                                             ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, stage,
                                              stage_stats, ls, &err);
                 if (rc != PTMI_OK) break;
                 if (overlap) {
@@ -562,8 +570,12 @@ int copy_out(ptmi_ctx* ctx, hipStream_t stream, const float* d_color, const floa
 // ---- RCCL, loaded at run time (the library has no link-time dependency on it) --------------------------------------------
 // north_star: "samples-per-pixel shard across the GPUs of one node with an RCCL reduce of the framebuffer over xGMI".  One
 // process drives all devices of a context, so the communicators come from ncclCommInitAll and the G reduce calls of an image
-// are one group.  PTMI_REDUCE=peer forces the peer-copy path; PTMI_REDUCE=rccl-always sends even a one-device context through
-// a one-rank communicator (how the tests exercise this code on a one-GPU box).
+// are one group.  OPT-IN (PTMI_REDUCE=rccl) until the collective has run on a node with two GPUs: the default sum is peer copies
+// + sum_images_kernel, whose order of additions is the device order ptmi.h documents; RCCL's order for more than two devices is
+// its algorithm's, so the image's last bits depend on the choice.  PTMI_REDUCE=rccl-always sends even a one-device context
+// through a one-rank communicator (how the tests exercise this code on a one-GPU box).  Any failure - library absent or of
+// another major version, initialisation refused, a run-time error of ncclReduce / ncclGroupEnd - falls back to the peer path for
+// the rest of the context's life (ptmi_rccl_state tells which path a context uses).
 struct RcclApi {
     void* lib = nullptr;
     int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
@@ -572,6 +584,8 @@ struct RcclApi {
     int (*GroupEnd)() = nullptr;
     int (*Reduce)(const void* send, void* recv, size_t count, int datatype, int op, int root, void* comm, hipStream_t stream) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int* version) = nullptr;
+    int version = 0;
     bool ok = false;
 };
 RcclApi& rccl_api()
@@ -591,7 +605,11 @@ RcclApi& rccl_api()
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
         api.Reduce = reinterpret_cast<decltype(api.Reduce)>(sym("ncclReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-        api.ok = api.CommInitAll && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Reduce;
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
+        // the enum values below are those of the NCCL 2 API (rccl.h of ROCm 7.2 reports 2.2x): another major version is refused
+        if (api.GetVersion && api.GetVersion(&api.version) != 0) api.version = 0;
+        const int major = api.version >= 10000 ? api.version / 10000 : api.version / 1000;
+        api.ok = api.CommInitAll && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Reduce && major == 2;
     });
     return api;
 }
@@ -643,7 +661,13 @@ int rccl_reduce_snapshots(ptmi_ctx* ctx, uint32_t slot)
     const int rc_end = api.GroupEnd();
     if (rc == 0) rc = rc_end;
     ON_DEVICE(ctx, ctx->dev[0]);
-    if (rc != 0) return fail(ctx, PTMI_ERR_HIP, std::string("ncclReduce: ") + (api.GetErrorString ? api.GetErrorString(rc) : "error"));
+    if (rc != 0) {
+        // a run-time refusal: remember why, never try again in this context, and let the caller sum through peer copies
+        ctx->err = std::string("ncclReduce: ") + (api.GetErrorString ? api.GetErrorString(rc) : "error") + " (falling back to peer copies)";
+        (void)hipGetLastError();
+        ctx->rccl_state = -1;
+        return PTMI_ERR_UNSUPPORTED;
+    }
     return PTMI_OK;
 }
 
@@ -669,10 +693,10 @@ int gather_snapshot(ptmi_ctx* ctx, uint32_t slot, const float** image)
         HIP_TRY(ctx, hipMalloc(&p, npix * 20));
         ctx->d_reduced = (float*)p;
     }
-    // Which path: the final image of a render (ptmi_read_image / ptmi_read_display: every device's share is new) goes through the
-    // collective; the images of a progressive per-image loop (ptmi_render_snapshots: ONE device's share is new per image) through
-    // the incremental peer copies below, which move 1 / (G - 1) of what a reduce would.  PTMI_REDUCE=rccl: the collective always.
-    const bool collective = slot == PTMI_MAX_SNAPSHOT_SLOTS - 1 || std::strncmp(reduce_mode(), "rccl", 4) == 0;
+    // Which path: peer copies + the sum kernel in device order, unless the caller opted into the collective (PTMI_REDUCE=rccl /
+    // rccl-always, above).  The images of a progressive per-image loop (ptmi_render_snapshots: ONE device's share is new per
+    // image) are cheaper through the incremental peer copies anyway, which move 1 / (G - 1) of what a reduce would.
+    const bool collective = std::strncmp(reduce_mode(), "rccl", 4) == 0;
     if (int rc = collective ? rccl_reduce_snapshots(ctx, slot) : (int)PTMI_ERR_UNSUPPORTED) {
         if (rc != PTMI_ERR_UNSUPPORTED) return rc;
         if (ctx->n_dev() == 1) {  // (rccl-always on a box without the library)
@@ -839,10 +863,12 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* sc)
 
     Relayout lay;
     if (int rc = build_layout(ctx, sc, lay)) return rc;
-    if (!lay.literal_kernel_reason.empty() && ctx->cfg.super_sampling)
-        return fail(ctx, PTMI_ERR_UNSUPPORTED, "SUPER_SAMPLING needs the wavefront kernel, which cannot reproduce the reference on this scene: " +
-                                                   lay.literal_kernel_reason);
     ctx->literal_kernel_reason = lay.literal_kernel_reason;
+    if (one_path_per_lane(ctx) && !(ctx->cfg.flags & PTMI_FLAG_MEGAKERNEL) && ctx->cfg.super_sampling) {
+        ctx->literal_kernel_reason.clear();
+        return fail(ctx, PTMI_ERR_UNSUPPORTED, "SUPER_SAMPLING needs the wavefront kernel, which cannot reproduce the reference on this scene with "
+                                               "the RANDOM sampler: " + lay.literal_kernel_reason);
+    }
     // a ray holds at most one pending far child per level it has descended
     ctx->stack_levels = lay.max_depth < 1 ? 1 : lay.max_depth;
     for (DeviceState& d : ctx->dev)
@@ -1122,6 +1148,7 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
     out->cycles_path = h[C_CYCLES_P]; out->cycles_loop = h[C_CYCLES_LOOP];
     out->leaf_item_violations = h[C_ITEM_VIOLATIONS];
     out->paths_retraced = h[C_RETRACED];
+    out->textured_hits = h[C_TEXTURED_HITS];
     return PTMI_OK;
 }
 

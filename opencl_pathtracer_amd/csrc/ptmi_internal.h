@@ -105,6 +105,8 @@ enum CounterSlot {
     C_CHK_RADIANCE,    // cl:951   the light gathered at a hit is non-negative
     C_CHK_HEMISPHERE,  // h:243    the scattered direction lies in the hemisphere of its normal after Vector_PutInSameHemisphereAs
     C_CHK_STATS_RANGE, // cl:1325,1330  a path's box / triangle test count fits the 5000-bin histograms
+    // surface hits on a material with a file texture (STATS builds): the texel term of SURVEY 8d's algorithmic bytes
+    C_TEXTURED_HITS,
     // paths a wavefront launch gave up (a ray that is not a number) and the literal loops traced again (every build)
     C_RETRACED,
     C_COUNT
@@ -140,6 +142,7 @@ struct DScene {
     uint32_t super_sampling;  // -D SUPER_SAMPLING
     uint32_t tris_precomputed; // tris[] holds DTriPre records
     uint32_t plain_shading;    // every material a plain-colour MAT_STANDART and every light a LIGHT_POINT
+    uint32_t nan_safe;         // the records can yield NaN distances (scene_needs_literal_kernel): the wavefront kernel's NANSAFE instantiation
     uint32_t n_records;        // nodes + leaf triangles in the one record array (nodes == tris)
     uint32_t wide_records;     // that array is 4 GB or more: byte offsets need 64 bits
     uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)
@@ -157,12 +160,11 @@ struct DScene {
                               void* stream, std::string* err);                                                                  \
     /* kernel_wavefront.hip: persistent wavefront state machine (default)                                                       \
        stack_levels = LDS traversal-stack entries per lane = depth of the uploaded tree (>= 1, <= 30) */                        \
-    int wavefront_resident_blocks##SUFFIX(int device, uint32_t stack_levels);                                                    \
     /* scene_in_device_memory = a device copy of `sc` (the kernel takes only the hot fields by value)                           \
        stage_stats: one word per staged path for the histograms (nullptr: the kernel issues the reference's atomics itself) */  \
     int launch_render_wavefront##SUFFIX(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,        \
                                         uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter,                \
-                                        int resident_blocks, uint32_t stack_levels, bool scheduler_stats, float* stage,         \
+                                        uint32_t stack_levels, bool scheduler_stats, float* stage,                              \
                                         uint32_t* stage_stats, void* stream, std::string* err);                                 \
     /* ... and what must follow it, in launch order: staged radiances -> accumulators, staged statistics -> histograms */       \
     int launch_accumulate_staged##SUFFIX(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,  \

@@ -458,6 +458,217 @@ def material_mix(width, height):
                  name="matmix")
 
 
+# --------------------------------------------------------------------------- the stand-in for BASELINE configs[4]
+
+def _grid_mesh(P, Nrm, UV, mat_pos, mat_neg=None, uv_night_scale=1.0):
+    """Triangles of a (nu+1) x (nv+1) vertex grid (two per cell, the cell's shorter diagonal is not chosen: a mesh as a
+    modeller's tessellation leaves it): per-vertex normals and uv as the importer copies them from the mesh."""
+    nu, nv = P.shape[0] - 1, P.shape[1] - 1
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    a, b, c, d = (i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)
+    corner = lambda A, k: A[k[0], k[1]]
+    tri_ix = [(a, b, c), (a, c, d)]
+    s = np.concatenate([np.stack([corner(P, k) for k in t], axis=1) for t in tri_ix]).astype(f32)
+    n = np.concatenate([np.stack([corner(Nrm, k) for k in t], axis=1) for t in tri_ix]).astype(f32)
+    uv = np.concatenate([np.stack([corner(UV, k) for k in t], axis=1) for t in tri_ix]).astype(f32)
+    # Triangle_isValid (MayaImporter.cpp:934-941): triangles with two equal vertices are not imported
+    ok = (np.any(s[:, 0] != s[:, 1], axis=-1) & np.any(s[:, 0] != s[:, 2], axis=-1) & np.any(s[:, 1] != s[:, 2], axis=-1))
+    s, n, uv = s[ok], n[ok], uv[ok]
+    return triangle_create(s[:, 0], s[:, 1], s[:, 2], normals=n, uvp=uv, uvn=(uv * f32(uv_night_scale)).astype(f32),
+                           mat_pos=mat_pos, mat_neg=mat_neg)
+
+
+def _cube_sphere(center, radius, n, mat_pos, mat_neg=None, uv_tiles=1.0):
+    """A sphere as six n x n patches of a cube pushed onto it (no poles, no zero-area triangles), smooth normals."""
+    t = np.linspace(-1.0, 1.0, n + 1)
+    u, v = np.meshgrid(t, t, indexing="ij")
+    one = np.ones_like(u)
+    faces = [(one, u, v), (-one, v, u), (v, one, u), (u, -one, v), (u, v, one), (v, u, -one)]
+    parts = []
+    for k, (x, y, z) in enumerate(faces):
+        d = np.stack([x, y, z], axis=-1)
+        d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        uv = np.stack([(u + 1) * 0.5 * uv_tiles + 0.37 * k, (v + 1) * 0.5 * uv_tiles + 0.21 * k], axis=-1)
+        parts.append(_grid_mesh(d * radius + np.asarray(center, np.float64), d, uv, mat_pos, mat_neg, uv_night_scale=2.0))
+    return parts
+
+
+def _noise_texture(rs, size, octaves, c0, c1, cell=0, alpha=0):
+    """size x size RGBA texels: value noise (bilinear, `octaves` octaves) between two colours, optionally under a grid of
+    `cell`-texel tiles with darker joints - what a photograph-based texture map is to the texel fetch: no two neighbours
+    equal."""
+    img = np.zeros((size, size))
+    amp, total = 1.0, 0.0
+    for o in range(octaves):
+        g = 4 << o
+        lat = rs.rand(g + 1, g + 1)
+        x = np.linspace(0, g, size, endpoint=False)
+        xi, xf = x.astype(int), x - x.astype(int)
+        xf = xf * xf * (3 - 2 * xf)
+        a = lat[xi][:, xi] * (1 - xf)[None, :] + lat[xi][:, xi + 1] * xf[None, :]
+        b = lat[xi + 1][:, xi] * (1 - xf)[None, :] + lat[xi + 1][:, xi + 1] * xf[None, :]
+        img += amp * (a * (1 - xf)[:, None] + b * xf[:, None])
+        total += amp
+        amp *= 0.55
+    img /= total
+    img = img + rs.uniform(-0.04, 0.04, img.shape)  # grain
+    if cell:
+        yy, xx = np.mgrid[0:size, 0:size]
+        joint = ((xx % cell) < 3) | (((yy + (xx // cell % 2) * (cell // 2)) % (cell // 2)) < 3)
+        img = np.where(joint, img * 0.45, img)
+    img = np.clip(img, 0, 1)[..., None]
+    rgb = (1 - img) * np.array(c0, np.float64) + img * np.array(c1, np.float64)
+    out = np.empty((size * size, 4), np.uint8)
+    out[:, :3] = np.clip(rgb, 0, 255).astype(np.uint8).reshape(-1, 3)
+    out[:, 3] = alpha
+    return out
+
+
+MAYALIKE_FULL = dict(terrain=560, sphere=64, torus=(256, 128), pond=128, wall=(192, 64))   # 1,094,144 triangles
+MAYALIKE_SMALL = dict(terrain=48, sphere=8, torus=(32, 16), pond=12, wall=(8, 4))           # 10,720 triangles: the CPU checker's size
+
+
+def maya_like(width, height, detail=None, texture_size=1024, sky_face=512):
+    """Stand-in for BASELINE configs[4] ("Maya-imported textured scene"; SURVEY 8d Config 5) - the importer needs the Maya SDK
+    and the reference ships no scene, so this builds what PathTracerMayaImporter would hand over for a modelled outdoor set,
+    following its conventions record by record:
+
+    * tessellated OBJECTS with shared smooth vertex normals and uv sets, not soup (ImportMesh, MayaImporter.cpp:177-308):
+      a 40 x 40 unit terrain of rolling hills (627 k triangles), six spheres, a torus, the rippled surface of a pond, three
+      sculpted brick walls;
+    * materials as CreateMaterials emits them (:606-690, :852-932): [0] the default grey for unknown shaders, Lambert ->
+      MAT_STANDART and Phong -> MAT_VARNHISHED, with and without a file texture; plus one each of the types the importer never
+      writes but the kernel implements (glass, water, metal), so the general shading code is all live;
+    * FOUR file textures of 1024 x 1024 RGBA texels (16 MB) behind the six 512 x 512 faces of the cube-map sky, which
+      comes first in texturesData as LoadSkyAndAllocateTextureMemory lays it out (:695-817), unpacked from a 2048 x 1536
+      horizontal cross by sky_from_cross;
+    * a point, a spot and a directional light (Light_Create, :819-850);
+    * z up (the importer's xyz -> zxy permutation applied), a 35 mm film-back camera through camera_from_film (SetCam, :59-101).
+    ``detail``: tessellation counts (MAYALIKE_FULL by default; MAYALIKE_SMALL keeps the same records at the CPU checker's size).
+    """
+    det = dict(MAYALIKE_FULL if detail is None else detail)
+    rs = np.random.RandomState(20240416)
+    # ---- sky: a horizontal cross, B G R bytes as the importer's BMP buffer holds them
+    fw = fh = int(sky_face)
+    cross = np.zeros((3 * fh, 4 * fw, 3), np.uint8)
+    yy, xx = np.mgrid[0:3 * fh, 0:4 * fw]
+    height_in_sky = 1.0 - yy / (3.0 * fh - 1)
+    clouds = (np.sin(xx * (2 * np.pi / (4 * fw)) * 7 + 3 * np.sin(yy * 0.011)) * np.sin(yy * 0.017 + 1.3) * 0.5 + 0.5) ** 3
+    clouds = clouds + rs.uniform(0, 0.05, clouds.shape)
+    sky_rgb = np.stack([90 + 120 * clouds + 40 * (1 - height_in_sky), 140 + 90 * clouds + 20 * (1 - height_in_sky),
+                        235 - 40 * height_in_sky + 20 * clouds], axis=-1)
+    ground = yy >= 2 * fh
+    sky_rgb = np.where(ground[..., None], np.stack([70 + 30 * clouds, 90 + 40 * clouds, 50 + 20 * clouds], axis=-1), sky_rgb)
+    cross[...] = np.clip(sky_rgb, 0, 255).astype(np.uint8)[..., ::-1]
+    sky, sky_texels = sky_from_cross(cross, first_texel=0)
+    sky["cosRotationAngle"], sky["sinRotationAngle"] = f32(np.cos(0.4)), f32(np.sin(0.4))
+    texels = [sky_texels]
+    textures = []
+
+    def add_tex(img):
+        off = sum(len(t) for t in texels)
+        texels.append(img)
+        textures.append((texture_size, texture_size, off))
+        return len(textures) - 1
+
+    ts = int(texture_size)
+    t_grass = add_tex(_noise_texture(rs, ts, 7, (40, 70, 25), (150, 190, 90)))
+    t_wood = add_tex(_noise_texture(rs, ts, 5, (90, 50, 20), (215, 160, 95)))
+    t_brick = add_tex(_noise_texture(rs, ts, 6, (120, 45, 35), (215, 120, 95), cell=128))
+    t_marble = add_tex(_noise_texture(rs, ts, 8, (235, 235, 230), (110, 115, 130)))
+
+    M = dict(default=0, grass=1, wood_phong=2, brick=3, marble_phong=4, red_phong=5, blue_lambert=6, glass=7, water=8, metal=9,
+             white_lambert=10)
+    mats = _records([
+        material_create(),                                                     # Material_Create(Material*), :852-861
+        material_create(S.MAT_STANDART, texture_id=t_grass),                   # Lambert + file texture
+        material_create(S.MAT_VARNHISHED, texture_id=t_wood),                  # Phong + file texture
+        material_create(S.MAT_STANDART, texture_id=t_brick),                   # Blinn -> MAT_STANDART (:910-932)
+        material_create(S.MAT_VARNHISHED, texture_id=t_marble),
+        material_create(S.MAT_VARNHISHED, color=(0.75, 0.12, 0.1, 0)),         # Phong, plain colour
+        material_create(S.MAT_STANDART, color=(0.15, 0.3, 0.8, 0)),            # Lambert, plain colour
+        material_create(S.MAT_GLASS, color=(0.92, 0.97, 1.0, 0), opacity=0.08),
+        material_create(S.MAT_WATER, color=(0.55, 0.75, 0.9, 0)),
+        material_create(S.MAT_METAL, color=(0.9, 0.88, 0.8, 0)),
+        material_create(S.MAT_STANDART, color=(0.8, 0.8, 0.8, 0)),             # the importer's 0.8 grey for black colours (:880)
+    ], S.Material)
+
+    def ground_z(x, y):
+        return (0.9 * np.sin(0.31 * x + 0.4) * np.cos(0.27 * y - 0.2) + 0.35 * np.sin(0.83 * x - 1.1) * np.sin(0.71 * y + 0.6)
+                + 0.12 * np.sin(2.3 * x + 0.3 * y) - 1.1 * np.exp(-((x - 5.0) ** 2 + (y + 3.0) ** 2) / 9.0))
+
+    parts = []
+    # terrain
+    n = int(det["terrain"])
+    t = np.linspace(-20.0, 20.0, n + 1)
+    X, Y = np.meshgrid(t, t, indexing="ij")
+    Z = ground_z(X, Y)
+    e = 1e-3
+    gx, gy = (ground_z(X + e, Y) - ground_z(X - e, Y)) / (2 * e), (ground_z(X, Y + e) - ground_z(X, Y - e)) / (2 * e)
+    nrm = np.stack([-gx, -gy, np.ones_like(gx)], axis=-1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    uv = np.stack([(X + 20.0) / 40.0 * 6.0, (Y + 20.0) / 40.0 * 6.0], axis=-1)
+    parts.append(_grid_mesh(np.stack([X, Y, Z], axis=-1), nrm, uv, M["grass"], M["default"], uv_night_scale=3.0))
+    # the pond: ripples over the hollow the terrain has at (5, -3); seen from above and from below
+    n = int(det["pond"])
+    t = np.linspace(-3.3, 3.3, n + 1)
+    X, Y = np.meshgrid(t + 5.0, t - 3.0, indexing="ij")
+    wave = lambda x, y: -0.55 + 0.02 * np.sin(3.1 * x) * np.cos(2.7 * y)
+    Z = wave(X, Y)
+    gx, gy = (wave(X + e, Y) - wave(X - e, Y)) / (2 * e), (wave(X, Y + e) - wave(X, Y - e)) / (2 * e)
+    nrm = np.stack([-gx, -gy, np.ones_like(gx)], axis=-1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    parts.append(_grid_mesh(np.stack([X, Y, Z], axis=-1), nrm, np.stack([X, Y], axis=-1) * 0.1, M["water"], M["water"]))
+    # six spheres standing on the terrain
+    n = int(det["sphere"])
+    for (x, y, r), (mp, mn, tiles) in zip([(-3.0, 2.0, 1.5), (0.5, -1.0, 1.2), (3.5, 3.5, 1.0), (-6.0, -3.0, 1.3), (-1.0, 6.5, 1.6), (8.0, 1.5, 1.1)],
+                                          [(M["wood_phong"], None, 2.0), (M["glass"], None, 1.0), (M["metal"], None, 1.0), (M["brick"], None, 3.0),
+                                           (M["red_phong"], M["white_lambert"], 1.0), (M["blue_lambert"], None, 1.0)]):
+        parts += _cube_sphere((x, y, float(ground_z(x, y)) + r * 0.96), r, n, mp, mn, uv_tiles=tiles)
+    # three brick walls around the set (the fourth side is where the camera stands): what is lit by the sky also lights its
+    # neighbours, so paths last - a modelled set is rarely a lone object under an open sky
+    nw, nh = det.get("wall", (8, 4))
+    for (x0, y0, x1, y1) in ((-12.0, 12.0, 12.0, 12.0), (-12.0, -14.0, -12.0, 12.0), (12.0, 12.0, 12.0, -14.0)):
+        sx, sz = np.meshgrid(np.linspace(0.0, 1.0, nw + 1), np.linspace(-2.5, 4.5, nh + 1), indexing="ij")
+        X, Y = x0 + (x1 - x0) * sx, y0 + (y1 - y0) * sx
+        bump = 0.03 * np.sin(37.0 * sx * (abs(x1 - x0) + abs(y1 - y0))) * np.sin(5.0 * sz)   # (not a plane: a wall that was sculpted)
+        nx, ny = (y1 - y0), -(x1 - x0)
+        ln = np.hypot(nx, ny)
+        nx, ny = nx / ln, ny / ln
+        P = np.stack([X + nx * bump, Y + ny * bump, sz], axis=-1)
+        Nw = np.broadcast_to(np.array([nx, ny, 0.0]), P.shape)
+        uvw = np.stack([sx * 6.0, (sz + 2.5) / 7.0 * 2.0], axis=-1)
+        parts.append(_grid_mesh(P, Nw, uvw, M["brick"], M["white_lambert"], uv_night_scale=1.0))
+    # a marble torus lying on the slope
+    nu, nv = det["torus"]
+    a, b = np.meshgrid(np.linspace(0, 2 * np.pi, nu + 1), np.linspace(0, 2 * np.pi, nv + 1), indexing="ij")
+    a[-1], b[:, -1] = a[0], b[:, 0]  # (closed exactly: the seam's vertices are the same numbers)
+    R, r0 = 2.2, 0.55
+    cx, cy = -7.5, 4.0
+    P = np.stack([cx + (R + r0 * np.cos(b)) * np.cos(a), cy + (R + r0 * np.cos(b)) * np.sin(a), float(ground_z(cx, cy)) + 0.75 + r0 * np.sin(b)], axis=-1)
+    Nn = np.stack([np.cos(b) * np.cos(a), np.cos(b) * np.sin(a), np.sin(b)], axis=-1)
+    au, bv = np.meshgrid(np.linspace(0, 4, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    parts.append(_grid_mesh(P, Nn, np.stack([au, bv], axis=-1), M["marble_phong"], None, uv_night_scale=1.0))
+    tris = _concat_tris(parts)
+
+    lights = _records([
+        light_point((2.0, -6.0, 7.0), color=(1, 0.95, 0.88, 1), power=55.0),
+        light_spot((-9.0, -5.0, 9.0), (0.6, 0.55, -1.0), cone_angle=0.9, penumbra_angle=0.25, color=(0.9, 0.92, 1, 1), intensity=2.5),
+        light_directional((-0.35, 0.45, -1.0), color=(1, 0.98, 0.9, 1), power=0.7),
+    ], S.Light)
+    eye = np.array([1.5, -17.0, 5.5])
+    view = np.array([-0.06, 1.0, -0.24])
+    view /= np.linalg.norm(view)
+    right = np.cross(view, [0, 0, 1.0])
+    right /= np.linalg.norm(right)
+    up = np.cross(right, view)
+    # Maya's default film back: 36 x 24 mm (1.417 x 0.945 in), 35 mm lens; the vertical aperture follows the image's aspect
+    pos, d, r, u = camera_from_film(eye, view, up, right, 35.0, 1.417, 1.417 * height / width)
+    return Scene(tris, lights, mats, np.array(textures, dtype=S.Texture), np.concatenate(texels), sky, pos, d, r, u,
+                 name="mayalike" if detail is None else "mayalike_s")
+
+
 FEATURES = ("plain", "glass", "water", "varnish", "varnish_textured", "textured", "metal", "two_sided", "fallback_normals",
             "spot", "directional", "cubemap")
 
@@ -792,6 +1003,10 @@ def build(name, width, height):
         return cornell_box(width, height)
     if name == "matmix":
         return material_mix(width, height)
+    if name == "mayalike":
+        return maya_like(width, height)
+    if name == "mayalike_s":
+        return maya_like(width, height, detail=MAYALIKE_SMALL)
     if name.startswith("feat_"):
         return feature_scene(name[5:], width, height)
     m = re.fullmatch(r"fuzz(\d+)(h?)(r?)_l(\d+)", name)

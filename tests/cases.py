@@ -13,6 +13,8 @@ CASES = {
     "matmix_96x96_d8_uni": ("matmix", S.UNIFORM, 96, 96, 8),
     "tris20k_96x64_d6": ("tris20k", S.JITTERED, 96, 64, 6),
     "tris1m_160x90_d10": ("tris1m", S.JITTERED, 160, 90, 10),
+    # scenes.maya_like at the CPU checker's size: the records of the configs[4] stand-in (1024x1024 file textures, 512x512 sky faces)
+    "mayalike_s_96x96_d8": ("mayalike_s", S.JITTERED, 96, 96, 8),
 }
 SMALL = [k for k in CASES if not k.startswith("tris1m")]
 FIXTURE_RANGES = [(0, 8), (8, 8)]  # (first iteration, count): two shards of a 16-spp render

@@ -13,6 +13,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _hip_device_present():
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Under `-m gpu` on a box with a GPU the reference-derived checkers (oracle/_ref: the reference kernel's code objects,
+    its builder, the launcher) are part of the test suite: without them every HIP-vs-reference comparison would vanish and
+    the run would still be green.  So their absence ends the session with an error, before any test runs."""
+    if not any("gpu" in item.keywords for item in items) or not _hip_device_present():
+        return
+    import oracle_ffi
+    if oracle_ffi.ALLOW_MISSING_REFERENCE:
+        return
+    missing = [os.path.relpath(p, ROOT) for p in oracle_ffi.configured_ref_objects() if not os.path.exists(p)]
+    if missing:
+        pytest.exit("reference-derived checkers are missing on a GPU box: " + ", ".join(missing[:6]) +
+                    (f" (+{len(missing) - 6} more)" if len(missing) > 6 else "") +
+                    " - build them where the reference tree exists (make -C oracle ref) and ship oracle/_ref/ with the "
+                    "repository, or set PTMI_ALLOW_MISSING_REFERENCE=1", returncode=3)
+
+
 @pytest.fixture(scope="session")
 def built():
     """Make sure the product library and the CPU oracle exist (both build without a GPU)."""

@@ -60,11 +60,13 @@ def fuzz_fixtures(out_dir):
     np.savez_compressed(os.path.join(out_dir, "ref_fuzz.npz"), **{k: np.array(v) for k, v in digests.items()})
 
 
-def main(out_dir, features_only=False, fuzz_only=False):
+def main(out_dir, features_only=False, fuzz_only=False, only=()):
     os.makedirs(out_dir, exist_ok=True)
     if fuzz_only:
         return fuzz_fixtures(out_dir)
     for case, (name, sampler, w, h, d) in ({} if features_only else cases.CASES).items():
+        if only and case not in only:
+            continue
         if not O.have_ref_kernel(case):
             print("skip", case, "(no code object)")
             continue
@@ -100,6 +102,8 @@ def main(out_dir, features_only=False, fuzz_only=False):
         one, _, _, _ = O.ref_gpu_render(case, sc, w, h, d, 1)
         out["it0_1_color"] = one
         np.savez_compressed(os.path.join(out_dir, f"ref_{case}.npz"), **out)
+    if only:
+        return
     # one kernel feature per scene through the strict build: digests of image, counts and histograms (8 spp each);
     # `<feature>_default`: the same through the default build (what the reference's own build line produces)
     fcase, fw, fh, fd = cases.FEATURE_CASE
@@ -119,5 +123,6 @@ def main(out_dir, features_only=False, fuzz_only=False):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    # usage: make_reference_fixtures.py [out_dir [case ...]] [--features-only | --fuzz-only]   (case names: only those cases)
     main(args[0] if args else os.path.join(ROOT, "gpurun_out", "golden"), features_only="--features-only" in sys.argv,
-         fuzz_only="--fuzz-only" in sys.argv)
+         fuzz_only="--fuzz-only" in sys.argv, only=tuple(args[1:]))

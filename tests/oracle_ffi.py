@@ -240,6 +240,32 @@ def have_ref_kernel(config_name, strict=False):
     return os.path.exists(REF_GPU_LIB) and os.path.exists(ref_kernel_path(config_name, strict))
 
 
+# A GPU box that received the repository without the reference-derived checkers must not report green with the whole
+# reference comparison gone: a missing object FAILS the test.  PTMI_ALLOW_MISSING_REFERENCE=1 (a third-party box that
+# cannot hold the reference's binaries) turns that into a skip again.
+ALLOW_MISSING_REFERENCE = os.environ.get("PTMI_ALLOW_MISSING_REFERENCE", "") not in ("", "0")
+
+
+def missing_reference(what):
+    import pytest
+    if ALLOW_MISSING_REFERENCE:
+        pytest.skip(what + " (PTMI_ALLOW_MISSING_REFERENCE is set)")
+    pytest.fail(what + ": build it where the reference tree exists (make -C oracle ref) and ship oracle/_ref/ with the "
+                "repository, or set PTMI_ALLOW_MISSING_REFERENCE=1 to skip the reference comparisons", pytrace=False)
+
+
+def configured_ref_objects():
+    """Every file `make -C oracle ref` leaves behind for the GPU tests: the launcher, the reference's builder and both builds
+    of every specialisation named in oracle/ref_configs.txt."""
+    paths = [REF_GPU_LIB, REF_BVH_LIB]
+    with open(os.path.join(ORACLE_DIR, "ref_configs.txt")) as f:
+        for line in f:
+            line = line.split("#")[0].split()
+            if line:
+                paths += [ref_kernel_path(line[0]), ref_kernel_path(line[0], strict=True)]
+    return paths
+
+
 def _local_size(n):
     for c in (8, 4, 2, 1):
         if n % c == 0:

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built):
                          check=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "ptmi_" in l and "_Z" not in l}
     assert exported == set(declared_symbols()), exported ^ set(declared_symbols())
-    assert lib.ptmi_abi_version() == 3
+    assert lib.ptmi_abi_version() == 4
 
 
 def test_headers_compile_as_c_and_cpp(tmp_path):

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 W, H, D, N_IDS = 40, 30, 3, 48
 
 
-SCENES = ["cornell", "fuzz3_l1", "fuzz5h_l1", "fuzz41hr_l1"]  # (one light each; the last two hold NaN-distance records: literal kernel)
+SCENES = ["cornell", "fuzz3_l1", "fuzz5h_l1", "fuzz41hr_l1"]  # (one light each; the last two hold NaN-distance records: the NANSAFE instantiation)
 
 
 @pytest.fixture(scope="module")

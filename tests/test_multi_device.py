@@ -202,8 +202,9 @@ def test_eight_listed_devices_equal_the_single_context(scene_factory):
 def test_rccl_reduce_behind_the_c_abi(scene_factory, monkeypatch):
     """The collective north_star names, reached through the reference API's readback: PTMI_REDUCE=rccl-always sends the image of
     a (one-device) context through librccl's ncclReduce - loaded at run time, one-rank communicator from ncclCommInitAll, on the
-    context's copy stream - before it crosses the bus.  (With several DISTINCT devices that path is the default for
-    ptmi_read_image; a one-GPU box can only check the plumbing and that the sum of one share is that share.)"""
+    context's copy stream - before it crosses the bus.  (With several DISTINCT devices PTMI_REDUCE=rccl opts into that path,
+    peer copies in device order being the default; a one-GPU box can only check the plumbing and that the sum of one share is
+    that share.)"""
     w, h, d, n = 64, 48, 4, 5
     sc = scene_factory("cornell", w, h)
     color, count, _, _ = render_scene(sc, w, h, d, n)

@@ -504,7 +504,7 @@ def test_vs_reference_kernel_on_gpu(case, scene_factory):
         distance to the default build IS the reference's own strict-vs-default distance: the two RMS figures are the same
         number, asserted with ==, no tolerance."""
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+        O.missing_reference("oracle/_ref code object not present (built only where the reference tree exists)")
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
     spp = 64
@@ -564,7 +564,7 @@ def test_north_star_rms_at_config_spp(case, spp, scene_factory):
     mode's distance to that build (= the reference's own strict-vs-default distance) is printed and recorded beside it
     (profiles/r03_north_star_rms.json is a copy of what this test writes on the GPU box)."""
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present")
+        O.missing_reference("oracle/_ref code object not present")
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
     r_color, r_count, _, _ = O.ref_gpu_render(case, sc, w, h, d, spp)
@@ -633,7 +633,8 @@ def test_fuzzed_scenes_in_every_other_mode_vs_oracle(seed):
             be.release()
         assert literal == (seed % 2 == 1)
         assert np.array_equal(color.view(np.uint32), base[0].view(np.uint32)) and np.array_equal(count, base[1])
-        assert st["leaf_item_violations"] == 0 and (st["trips_node"] > 0) == (not literal)
+        # (round 4: a scene whose records yield NaN distances runs the wavefront kernel too - its NANSAFE instantiation)
+        assert st["leaf_item_violations"] == 0 and st["trips_node"] > 0
         # one GPU listed twice: sample counts, counters and histograms of the single context; the image up to the association
         # of the two partial sums (NaN pixels of a hostile scene stay NaN)
         two = render_scene(sc, w, h, d, 5, flags=f, devices=[0, 0])

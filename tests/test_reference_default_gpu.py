@@ -92,7 +92,7 @@ def _assert_equal_to_reference(ours, ref, what):
 @pytest.mark.parametrize("case", list(cases.CASES))
 def test_bit_exact_vs_reference_default_build(case, scene_factory):
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+        O.missing_reference("oracle/_ref code object not present (built only where the reference tree exists)")
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
     spp = 16
@@ -108,14 +108,16 @@ def test_every_feature_bit_exact_vs_reference_default_build(feature):
     each: all five material branches, every light type, every division / square root / contraction site of the kernel."""
     case, w, h, d = "feat_64x64_d8", 64, 64, 8
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present")
+        O.missing_reference("oracle/_ref code object not present")
     sc = bvh_create(scenes.build("feat_" + feature, w, h))
     ref = O.ref_gpu_render(case, sc, w, h, d, 256)
     _assert_equal_to_reference(render_scene(sc, w, h, d, 256, flags=DA), ref, feature)
 
 
 FULL_SIZE = {"cornell_512x512_d4": ("cornell", S.JITTERED, 512, 512, 4, 8),          # BASELINE configs[0]
-             "matmix_3840x2160_d16": ("matmix", S.JITTERED, 3840, 2160, 16, 1),     # the stand-in for configs[4]: 4K, 16 bounces, 3 lights
+             "matmix_3840x2160_d16": ("matmix", S.JITTERED, 3840, 2160, 16, 1),     # the toy material mix at configs[4]'s size: 4K, 16 bounces, 3 lights
+             # the stand-in for BASELINE configs[4] (SURVEY 8d Config 5): 1.09 M textured triangles, 4 x 1024^2 textures, 6 x 512^2 sky
+             "mayalike_3840x2160_d16": ("mayalike", S.JITTERED, 3840, 2160, 16, 1),
              "tris1m_1920x1080_d10": ("tris1m", S.JITTERED, 1920, 1080, 10, 2),   # BASELINE configs[2]: the bench workload
              "cornell_1920x1080_d8": ("cornell", S.JITTERED, 1920, 1080, 8, 4)}     # BASELINE configs[1]
 
@@ -125,7 +127,7 @@ def test_full_size_bit_exact_vs_reference_default_build(case):
     """BASELINE's own image size, scene and ray depth: all 2 M pixels, the sample counts and the three histograms equal the
     reference kernel as its own build line compiles it, run beside the integrator on this GPU."""
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+        O.missing_reference("oracle/_ref code object not present (built only where the reference tree exists)")
     name, sampler, w, h, d, spp = FULL_SIZE[case]
     sc = bvh_create(scenes.build(name, w, h))
     ref = O.ref_gpu_render(case, sc, w, h, d, spp)
@@ -138,7 +140,7 @@ def test_four_million_triangles_bit_exact_vs_reference_default_build():
     light count only, so the 1M-triangle configuration's kernel renders this scene too.  1920x1080, 1 spp."""
     case = "tris1m_1920x1080_d10"
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present (built only where the reference tree exists)")
+        O.missing_reference("oracle/_ref code object not present (built only where the reference tree exists)")
     w, h, d = 1920, 1080, 10
     sc = bvh_create(scenes.build("tris4m", w, h))
     assert sc.bvhMaxDepth >= 23
@@ -173,7 +175,7 @@ def test_random_sampler_vs_reference_default_build(scene_factory):
     agree where no update was lost."""
     case = "cornell_64x48_d4_rnd"
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present")
+        O.missing_reference("oracle/_ref code object not present")
     w, h, d, n = 64, 48, 4, 8
     sc = scene_factory("cornell", w, h)
     r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, n)
@@ -214,7 +216,7 @@ def test_fuzzed_scenes_bit_exact_vs_both_reference_builds(seed, hostile):
 
     for n_lights, case, w, h, d in FUZZ_SPECIALISATIONS:
         if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
-            pytest.skip("oracle/_ref code objects not present")
+            O.missing_reference("oracle/_ref code objects not present")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")  # (the hostile scenes divide 0 by 0 on purpose, as the importer would)
             sc = bvh_create(scenes.build(f"fuzz{seed}{'h' if hostile else ''}_l{n_lights}", w, h))
@@ -230,16 +232,19 @@ def test_fuzzed_scenes_bit_exact_vs_both_reference_builds(seed, hostile):
     assert not problems, "\n".join(problems)
 
 
-def test_scenes_with_nan_distances_go_to_the_literal_kernel():
+def test_scenes_with_nan_distances_run_the_nan_safe_wavefront_kernel(monkeypatch):
     """A zero-area triangle (N = 0/0 as the importer computes it) is ACCEPTED by the reference for every ray that reaches it, with
-    a NaN distance; the context then serves the scene with the one-path-per-lane kernel - for ptmi_render and for
-    ptmi_render_snapshots alike - says why, and refuses SUPER_SAMPLING (wavefront kernel only) instead of rendering other pixels."""
+    a NaN distance.  Round 4: the context says why the scene is special and renders it with the wavefront kernel's NANSAFE
+    instantiation - only the paths that REACH such a record are given up and traced again by the literal loops - for ptmi_render
+    and ptmi_render_snapshots alike: the images equal the one-path-per-lane kernel's (the reference's loops as they are written)
+    and the reference kernel's own.  With the RANDOM sampler nothing is staged, so the one-path-per-lane kernel takes the scene as
+    a whole (and SUPER_SAMPLING, wavefront-only, is refused there)."""
     import warnings
     case, w, h, d = "feat_64x64_d8", 64, 64, 8
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         tame, wild = bvh_create(scenes.build("fuzz3_l1", w, h)), bvh_create(scenes.build("fuzz3h_l1", w, h))
-    be = backend.Backend().setup_context(w, h, d, 1, S.JITTERED, flags=DA)
+    be = backend.Backend().setup_context(w, h, d, 1, S.JITTERED, flags=DA | backend.FLAG_SCHEDULER_STATS)
     try:
         be.initialize_memory(tame)
         assert be.literal_kernel_reason() is None
@@ -248,6 +253,8 @@ def test_scenes_with_nan_distances_go_to_the_literal_kernel():
         be.render_snapshots(0, 6, 0)
         images = [be.read_snapshot(k) for k in range(6)]
         stats = be.read_statistics()
+        st = be.scheduler_stats()
+        assert st["trips_node"] > 0 and st["paths_retraced"] > 0, "the wavefront kernel ran and handed paths to the literal loops"
         be.initialize_memory(tame)
         assert be.literal_kernel_reason() is None
     finally:
@@ -257,11 +264,39 @@ def test_scenes_with_nan_distances_go_to_the_literal_kernel():
     assert all(np.array_equal(a, b) for a, b in zip(stats, ref_stats))
     c3, n3, _, _ = render_scene(wild, w, h, d, 3, flags=DA | backend.FLAG_MEGAKERNEL)
     assert np.array_equal(images[2][0].view(np.uint32), c3.view(np.uint32)) and np.array_equal(images[2][1], n3)
-    if O.have_ref_kernel(case):
-        r_color, r_count, _, _ = O.ref_gpu_render(case, wild, w, h, d, 6)
-        assert np.array_equal(r_color.view(np.uint32), color.view(np.uint32)) and np.array_equal(r_count, count)
+    # the production instantiation (no statistics), both arithmetics, counters included
+    for flags in (DA, 0):
+        lit = render_scene(wild, w, h, d, 6, flags=flags | backend.FLAG_MEGAKERNEL)
+        ours = render_scene(wild, w, h, d, 6, flags=flags)
+        assert np.array_equal(ours[0].view(np.uint32), lit[0].view(np.uint32)) and np.array_equal(ours[1], lit[1]) and ours[3] == lit[3]
+        assert all(np.array_equal(a, b) for a, b in zip(ours[2], lit[2]))
+    if not O.have_ref_kernel(case):
+        O.missing_reference("oracle/_ref code object not present")
+    r_color, r_count, _, _ = O.ref_gpu_render(case, wild, w, h, d, 6)
+    assert np.array_equal(r_color.view(np.uint32), color.view(np.uint32)) and np.array_equal(r_count, count)
+    # PTMI_LITERAL_KERNEL=1: the scene as a whole on the one-path-per-lane kernel, as before round 4
+    monkeypatch.setenv("PTMI_LITERAL_KERNEL", "1")
+    forced = render_scene(wild, w, h, d, 6, flags=DA)
+    monkeypatch.delenv("PTMI_LITERAL_KERNEL")
+    assert np.array_equal(forced[0].view(np.uint32), color.view(np.uint32))
+    # RANDOM sampler + SUPER_SAMPLING on such a scene: refused, not rendered differently
     with pytest.raises(backend.PtmiError, match="SUPER_SAMPLING"):
-        render_scene(wild, w, h, d, 2, flags=DA, super_sampling=True)
+        render_scene(wild, w, h, d, 2, flags=DA, super_sampling=True, sampler=S.RANDOM)
+
+
+def test_super_sampling_on_a_scene_with_nan_distances():
+    """SUPER_SAMPLING (wavefront kernel only) on a scene with zero-area triangles - refused before round 4 - equals the reference
+    kernel built -D SUPER_SAMPLING with its own options: images, sampling-density map and histograms."""
+    import warnings
+    case, w, h, d = "cornell_64x48_d4_ss", 64, 48, 4
+    if not O.have_ref_kernel(case):
+        O.missing_reference("oracle/_ref code object not present")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wild = bvh_create(scenes.build("fuzz3h_l1", w, h))
+    ours = render_scene(wild, w, h, d, 12, flags=DA, super_sampling=True)
+    ref = O.ref_gpu_render(case, wild, w, h, d, 12)
+    _assert_equal_to_reference(ours, ref, "fuzz3h_l1 with SUPER_SAMPLING")
 
 
 # (reference code object, lights, sampler, W, H, depth, SUPER_SAMPLING)
@@ -280,7 +315,7 @@ def test_fuzzed_scenes_other_samplers_sizes_and_depths(seed):
     case, n_lights, sampler, w, h, d, ss = FUZZ_OTHER_SPECIALISATIONS[seed % len(FUZZ_OTHER_SPECIALISATIONS)]
     hostile = seed % 2 == 1 and not ss
     if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
-        pytest.skip("oracle/_ref code objects not present")
+        O.missing_reference("oracle/_ref code objects not present")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         sc = bvh_create(scenes.build(f"fuzz{seed}{'h' if hostile else ''}_l{n_lights}", w, h))
@@ -309,7 +344,7 @@ def test_fuzzed_scenes_with_records_no_importer_writes(seed):
     problems = []
     for n_lights, case, w, h, d in FUZZ_SPECIALISATIONS:
         if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
-            pytest.skip("oracle/_ref code objects not present")
+            O.missing_reference("oracle/_ref code objects not present")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             sc = bvh_create(scenes.build(f"fuzz{seed}{'h' if seed % 2 else ''}r_l{n_lights}", w, h))
@@ -328,22 +363,38 @@ def test_fuzzed_scenes_with_records_no_importer_writes(seed):
     assert not problems, "\n".join(problems)
 
 
-@pytest.mark.parametrize("name", ["fuzz3_l1", "fuzz47r_l1", "fuzz7h_l1"])
+@pytest.mark.parametrize("name", ["fuzz3_l1", "fuzz47r_l1", "fuzz3h_l1", "fuzz7h_l1"])
 def test_fuzzed_scenes_at_full_size_vs_reference_default_build(name):
     """1920 x 1080, depth 10 (the code object of BASELINE configs[2]: the reference bakes in sizes, depth and light count, not
     the scene): thousands of triangles in clusters with every material type and textures - the GENERAL shading specialisation
     of the wavefront kernel at full size, which the two BASELINE scenes (plain ones) do not reach -, the same with corrupted
-    records (where a few paths in a million meet a ray that is not a number), and a hostile one through the one-path-per-lane
-    kernel.  All 2 M pixels, counts and histograms equal."""
+    records (where a few paths in a million meet a ray that is not a number), and two hostile ones (zero-area triangles: NaN
+    distances) through the wavefront kernel's NANSAFE instantiation, against BOTH builds of the reference.  All 2 M pixels, counts
+    and histograms equal."""
     import warnings
     case, w, h, d, spp = "tris1m_1920x1080_d10", 1920, 1080, 10, 2
     if not O.have_ref_kernel(case):
-        pytest.skip("oracle/_ref code object not present")
+        O.missing_reference("oracle/_ref code object not present")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         sc = bvh_create(scenes.build(name, w, h))
     ours = render_scene(sc, w, h, d, spp, flags=DA)
     _assert_equal_to_reference(ours, O.ref_gpu_render(case, sc, w, h, d, spp), name)
+    if "h" in name.split("_")[0]:
+        if not O.have_ref_kernel(case, strict=True):
+            O.missing_reference("oracle/_ref strict code object not present")
+        _assert_equal_to_reference(render_scene(sc, w, h, d, spp, flags=0), O.ref_gpu_render(case, sc, w, h, d, spp, strict=True), name + " (strict)")
+        be = backend.Backend().setup_context(w, h, d, 1, S.JITTERED, flags=DA | backend.FLAG_SCHEDULER_STATS)
+        try:
+            be.initialize_memory(sc)
+            assert be.literal_kernel_reason() is not None
+            be.render(0, 1)
+            be.synchronize()
+            st = be.scheduler_stats()
+        finally:
+            be.release()
+        # the wavefront kernel rendered it, and only the paths that reached a bad record went to the literal loops
+        assert st["trips_node"] > 0 and 0 < st["paths_retraced"] < w * h // 2, st
     if name == "fuzz47r_l1":
         # 15 of its 4 M paths scatter into a direction that is not a number (a refraction's square root of a negative): the
         # wavefront kernel gives those up and the literal loops trace them again behind the launch - the reference's pixels
@@ -370,7 +421,7 @@ def test_fuzzed_scenes_with_corrupted_trees(seed):
     problems = []
     for n_lights, case, w, h, d in FUZZ_SPECIALISATIONS:
         if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
-            pytest.skip("oracle/_ref code objects not present")
+            O.missing_reference("oracle/_ref code objects not present")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             sc = scenes.corrupt_tree(bvh_create(scenes.build(f"fuzz{seed}{'h' if seed % 3 == 0 else ''}{'r' if seed % 2 else ''}_l{n_lights}", w, h)), seed)

@@ -29,7 +29,7 @@ def test_device_math_is_the_platform_library():
     """ptmi_sincosf (device build) == the device library's sinf/cosf on [0, 2 pi] and beyond; the oracle's table-driven
     v_rsq_f32 == the instruction, for inputs over the whole normal range."""
     if not os.path.exists(PROBE):
-        pytest.skip("oracle/build/libdevice_math_probe.so not built (make -C oracle probe)")
+        pytest.fail("oracle/build/libdevice_math_probe.so not built (make -C oracle probe)", pytrace=False)
     lib = C.CDLL(PROBE)
     rs = np.random.RandomState(11)
     theta = np.concatenate([np.linspace(0, 2 * np.pi, 200001), rs.uniform(0, 2 * np.pi, 300000), rs.uniform(-50, 50, 100000),
@@ -65,7 +65,7 @@ STRICT_CASES = [c for c in cases.CASES]
 @pytest.mark.parametrize("case", STRICT_CASES)
 def test_bit_exact_vs_reference_strict_build(case, scene_factory):
     if not O.have_ref_kernel(case, strict=True):
-        pytest.skip("oracle/_ref strict code object not present (built only where the reference tree exists)")
+        O.missing_reference("oracle/_ref strict code object not present (built only where the reference tree exists)")
     name, sampler, w, h, d = cases.CASES[case]
     sc = scene_factory(name, w, h)
     spp = 16
@@ -86,7 +86,7 @@ def test_full_size_bit_exact_vs_reference_strict_build(case):
     """BASELINE's own image size, scene and ray depth: every one of the 2 M pixels, the sample counts and the three
     histograms of the default (wavefront) kernel equal the reference kernel's strict build run beside it on this GPU."""
     if not O.have_ref_kernel(case, strict=True):
-        pytest.skip("oracle/_ref strict code object not present (built only where the reference tree exists)")
+        O.missing_reference("oracle/_ref strict code object not present (built only where the reference tree exists)")
     name, sampler, w, h, d, spp = FULL_SIZE[case]
     sc = bvh_create(scenes.build(name, w, h))
     r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, spp, strict=True)
@@ -103,7 +103,7 @@ def test_every_feature_bit_exact_vs_reference_strict_build(feature):
     each, all five material branches, every light type, and the pixels whose seeds are degenerate."""
     case, w, h, d = "feat_64x64_d8", 64, 64, 8
     if not O.have_ref_kernel(case, strict=True):
-        pytest.skip("oracle/_ref strict code object not present")
+        O.missing_reference("oracle/_ref strict code object not present")
     sc = bvh_create(scenes.build("feat_" + feature, w, h))
     r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, 256, strict=True)
     color, count, (dep, bbx, tri), _ = render_scene(sc, w, h, d, 256)
