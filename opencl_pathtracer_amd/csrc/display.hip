@@ -64,7 +64,27 @@ __global__ void __launch_bounds__(256) sum_images_kernel(float* __restrict__ out
 
 }  // namespace ptmi_dev
 
+namespace ptmi_dev {
+// dst[i] += src[i]: the counter block of a launch that ran on a stage set of its own, added when the main stream adopts it
+__global__ void add_counters_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, uint32_t n)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+}  // namespace ptmi_dev
+
 namespace ptmi_internal {
+
+int launch_add_counters(unsigned long long* dst, const unsigned long long* src, uint32_t n, void* stream, std::string* err)
+{
+    hipLaunchKernelGGL(ptmi_dev::add_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, src, n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("add_counters_kernel launch: ") + hipGetErrorString(e);
+        return PTMI_ERR_HIP;
+    }
+    return PTMI_OK;
+}
 
 int launch_sum_images(float* out, const float* const* parts, uint32_t n_parts, size_t n_floats, void* stream, std::string* err)
 {

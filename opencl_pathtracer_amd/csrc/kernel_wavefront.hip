@@ -938,6 +938,11 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
 // again by the reference's loops as they are written (ptmi_literal_path.hpp): radiance, statistics word and totals as if the
 // launch had traced them.  Runs behind every staged wavefront launch on its stream and returns at once unless the launch
 // left a non-zero word 1 in its job-counter block.
+// The marked slots are few and scattered (a handful per launch in a clean scene; a few per cent where rays meet a record that
+// yields NaN distances), so a wave does not trace the slots it scans: it COLLECTS marked slot numbers in an LDS queue of its
+// own while it scans (64 slots per step, chunks dealt out to the waves of the grid in turn) and traces them 64 at a time, all
+// lanes busy - round 4; traced where they were found, one lane in fifteen worked and a scene with 7 % of its paths marked ran
+// at the one-path-per-lane kernel's pace.
 template <bool PRE>
 __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, const uint32_t first_iteration, const uint32_t n_iterations,
                                                                const uint32_t iteration_stride, float* __restrict__ stage,
@@ -946,13 +951,12 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
     if (__builtin_nontemporal_load(&job_counter[1]) == 0u) return;  // (the same for every lane of the grid)
     __shared__ uint32_t stack_mem[kStackDepth * kBlock];
     __shared__ unsigned long long block_counters[C_TRI + 1];  // (two's complement: the one segment the launch counted is taken back)
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t queues[kBlock / 64][128];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (tid <= C_TRI) block_counters[tid] = 0;
     __syncthreads();
     const uint32_t n_pixels = sc.width * sc.height, n_slots = n_pixels * n_iterations;
-    for (uint32_t slot = blockIdx.x * kBlock + tid; slot < n_slots; slot += gridDim.x * kBlock) {
-        const uint4 v = reinterpret_cast<const uint4*>(stage)[slot];
-        if (v.x != kPoisonMarker || v.y != kPoisonMarker || v.z != kPoisonMarker || v.w != kPoisonMarker) continue;
+    auto trace_slot = [&](const uint32_t slot) {
         const uint32_t it_local = slot / n_pixels, pixel = slot - it_local * n_pixels;
         const uint32_t gy = pixel / sc.width, gx = pixel - gy * sc.width;
         const uint32_t it = first_iteration + it_local * iteration_stride;
@@ -976,7 +980,30 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
         atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
         atomicAdd(&block_counters[C_BBX], (unsigned long long)pc.bbx);
         atomicAdd(&block_counters[C_TRI], (unsigned long long)pc.tri);
+    };
+    uint32_t* const queue = queues[tid >> 6];
+    uint32_t queued = 0;  // wave-uniform: slots waiting in this wave's queue (< 64 between two steps)
+    const uint32_t n_waves = gridDim.x * (kBlock / 64), n_chunks = (n_slots + 63u) / 64u;
+    for (uint32_t chunk = blockIdx.x * (kBlock / 64) + (tid >> 6); chunk < n_chunks; chunk += n_waves) {
+        const uint32_t slot = chunk * 64u + lane;
+        bool marked = false;
+        if (slot < n_slots) {
+            const uint4 v = reinterpret_cast<const uint4*>(stage)[slot];
+            marked = v.x == kPoisonMarker && v.y == kPoisonMarker && v.z == kPoisonMarker && v.w == kPoisonMarker;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(marked);
+        if (m == 0ull) continue;
+        if (marked) queue[queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = slot;
+        queued += (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the queue is read by other lanes of the wave than wrote it)
+        if (queued >= 64u) {
+            queued -= 64u;
+            const uint32_t mine = queue[queued + lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            trace_slot(mine);
+        }
     }
+    if (lane < queued) trace_slot(queue[lane]);
     __syncthreads();
     if (tid > C_PATHS && tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
     if (tid == C_PATHS && block_counters[tid] != 0ull) atomicAdd(&sc.counters[C_RETRACED], block_counters[tid]);
@@ -1159,7 +1186,7 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         int device = 0;
         const bool cached_device = hipGetDevice(&device) == hipSuccess && device >= 0 && device < kMaxCachedDevices;
         const bool plain = sc.tris_precomputed && sc.plain_shading && sc.sampler == PTMI_SAMPLER_JITTERED && !sc.russian_roulette &&
-                           sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats && !sc.nan_safe;
+                           sc.n_lights == 1 && !sc.super_sampling && !scheduler_stats;
         warm.wait_debt = lv >= 16u ? 768u : (plain ? 320u : 512u);  // (the cheaper a path-logic pass, the sooner it pays)
         // the persistent grid of the chosen instantiation on the CURRENT device (instantiations differ in registers, devices in
         // CUs and partition mode, hence in workgroups held at once): asked once per (instantiation, device, stack levels);
@@ -1188,7 +1215,9 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         } else if (scheduler_stats) {
             if (sc.tris_precomputed) PTMI_LAUNCH_WF(true, true, false, true); else PTMI_LAUNCH_WF(true, false, false, true);
         } else if (sc.nan_safe) {
-            if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, true); else PTMI_LAUNCH_WF(false, false, false, true);
+            if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true, true);
+            else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, true);
+            else PTMI_LAUNCH_WF(false, false, false, true);
         } else {
             if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true, false);  // the common case, BASELINE's untextured scenes among them
             else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, false);

@@ -12,6 +12,7 @@
 #include <limits>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -56,12 +57,29 @@ struct DeviceState {
     // finish one by one).  What keeps the results those of sequential launches: the staged values reach the accumulators
     // on the ONE main stream, launch after launch (launch_accumulate_staged), and set k % 2 is reused by launch k + 2
     // only after launch k's have been added (stage_free).
-    float* d_stage[2] = {nullptr, nullptr};
-    size_t stage_iterations = 0;
-    hipStream_t launch_stream[2] = {nullptr, nullptr};
-    hipEvent_t rendered[2] = {nullptr, nullptr};    // recorded on launch_stream[i] behind the kernel
-    hipEvent_t stage_free[2] = {nullptr, nullptr};  // recorded on the main stream behind the accumulation
-    bool stage_busy[2] = {false, false};
+    // (round 4: FOUR sets.  Set 0 is sized for the longest launch and is the one long launches use, on the main stream; short
+    // launches - fewer than 4 iterations - take the sets in turn, each with a COUNTER BLOCK and a device copy of the scene
+    // record of its own, so that such a launch touches nothing of the context but its set until the main stream ADOPTS it:
+    // adds its staged radiances to the accumulators, its statistics words to the histograms, its counter block to the
+    // counters.  That is what lets the library RENDER AHEAD of a caller that asks for one image per call and waits for it, as
+    // the reference's loop does, OpenCL.cpp:76-107: the launches of the next calls are already running when they are asked
+    // for - `ahead` - and are dropped without a trace if the caller asks for something else.)
+    static constexpr int kStageSets = 4;
+    float* d_stage[kStageSets] = {};
+    size_t stage_cap[kStageSets] = {};            // iterations a set holds
+    hipStream_t launch_stream[kStageSets] = {};
+    hipEvent_t rendered[kStageSets] = {};         // recorded on launch_stream[i] behind the kernel
+    hipEvent_t stage_free[kStageSets] = {};       // recorded on the main stream behind the accumulation
+    hipEvent_t reuse_after[kStageSets] = {};      // what the set's next launch waits for: stage_free (adopted) or rendered (dropped)
+    unsigned long long* d_set_counters[kStageSets] = {};  // [C_COUNT] each
+    DScene* d_scene_set[kStageSets] = {};         // ds with .counters = the set's block
+    struct Ahead { uint32_t first, n, stride; int set; };
+    std::deque<Ahead> ahead;                      // launches in flight that no call has asked for yet, oldest first
+    uint32_t next_set = 0;
+    // the previous ptmi_render call on this device: launches only run ahead of a caller that has been SEEN to continue where
+    // it left off (ids first + n, same n), so a caller that jumps around pays nothing
+    bool have_last = false;
+    uint32_t last_first = 0, last_n = 0, last_stride = 0;
     uint32_t launches_issued = 0;
     DScene ds{};
     DScene* d_scene = nullptr;  // device copy of ds (what the wavefront kernel's path logic reads)
@@ -160,8 +178,10 @@ void free_scene_memory(ptmi_ctx* ctx)
         (void)hipSetDevice(d.device);
         // every stream that may still run a kernel or a copy on this memory - the launch streams too: after a failure between a
         // launch and the main stream's wait for it (render_on_device) a persistent kernel may still be reading the scene
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < DeviceState::kStageSets; i++)
             if (d.launch_stream[i]) (void)hipStreamSynchronize(d.launch_stream[i]);
+        d.ahead.clear();
+        d.have_last = false;
         (void)hipStreamSynchronize(d.stream);
         if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
         for (void* p : d.allocations) (void)hipFree(p);
@@ -171,12 +191,14 @@ void free_scene_memory(ptmi_ctx* ctx)
         d.d_counters = nullptr;
         d.d_job_counter = nullptr;
         d.d_scene = nullptr;
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < DeviceState::kStageSets; i++) {
             if (d.d_stage[i]) (void)hipFree(d.d_stage[i]);
             d.d_stage[i] = nullptr;
-            d.stage_busy[i] = false;
+            d.stage_cap[i] = 0;
+            d.reuse_after[i] = nullptr;
+            d.d_set_counters[i] = nullptr;
+            d.d_scene_set[i] = nullptr;
         }
-        d.stage_iterations = 0;
         for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++) {
             if (d.d_snapshot[k]) (void)hipFree(d.d_snapshot[k]);
             d.d_snapshot[k] = nullptr;
@@ -236,6 +258,18 @@ int build_layout(ptmi_ctx* ctx, const ptmi_scene* sc, Relayout& out)
     return rc == PTMI_OK ? rc : fail(ctx, rc, err);
 }
 
+// The device copies of d.ds: the context's, and one per stage set whose launches count into the set's own block.
+int upload_scene_records(ptmi_ctx* ctx, DeviceState& d)
+{
+    HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
+    for (int i = 0; i < DeviceState::kStageSets; i++) {
+        DScene k = d.ds;
+        k.counters = d.d_set_counters[i];
+        HIP_TRY(ctx, hipMemcpy(d.d_scene_set[i], &k, sizeof(DScene), hipMemcpyHostToDevice));
+    }
+    return PTMI_OK;
+}
+
 int fold_events(ptmi_ctx* ctx, DeviceState& d)
 {
     ON_DEVICE(ctx, d);
@@ -282,13 +316,20 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     if (int rc = device_alloc(ctx, d, npix * 16, &dc)) return rc;
     if (int rc = device_alloc(ctx, d, npix * 4, &dn)) return rc;
     if (int rc = device_alloc(ctx, d, hist_words * 4, &dh)) return rc;
-    // counters, then two sets of job-queue counters (256-byte aligned, up to 8 x 1024 dwords apart)
-    if (int rc = device_alloc(ctx, d, C_COUNT * 8 + 256 + 2 * 8 * 1024 * 4, &dk)) return rc;
-    if (int rc = device_alloc(ctx, d, sizeof(DScene), &dsc)) return rc;
+    // counters, then one set of job-queue counters per stage set (256-byte aligned, up to 8 x 1024 dwords apart), then the
+    // stage sets' counter blocks and scene records
+    constexpr size_t kCounterBlock = ((C_COUNT * 8 + 255) / 256) * 256, kSceneBlock = ((sizeof(DScene) + 255) / 256) * 256;
+    constexpr int kSets = DeviceState::kStageSets;
+    if (int rc = device_alloc(ctx, d, kCounterBlock + 256 + kSets * 8 * 1024 * 4 + kSets * kCounterBlock, &dk)) return rc;
+    if (int rc = device_alloc(ctx, d, (1 + kSets) * kSceneBlock, &dsc)) return rc;
     d.d_scene = (DScene*)dsc;
     d.d_color = (float*)dc; d.d_count = (float*)dn; d.d_hist = (uint32_t*)dh;
     d.d_counters = (unsigned long long*)dk;
-    d.d_job_counter = (uint32_t*)((char*)dk + ((C_COUNT * 8 + 255) / 256) * 256);
+    d.d_job_counter = (uint32_t*)((char*)dk + kCounterBlock);
+    for (int i = 0; i < kSets; i++) {
+        d.d_set_counters[i] = (unsigned long long*)((char*)dk + kCounterBlock + kSets * 8 * 1024 * 4 + i * kCounterBlock);
+        d.d_scene_set[i] = (DScene*)((char*)dsc + (1 + i) * kSceneBlock);
+    }
 
     ds.image_color = d.d_color;
     ds.image_ray_nb = d.d_count;
@@ -323,7 +364,7 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     ds.sampler = ctx->cfg.sampler;
     ds.russian_roulette = (ctx->cfg.flags & PTMI_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u;
     ds.source_seed = (ctx->cfg.flags & PTMI_FLAG_SOURCE_SEED) ? 1u : 0u;
-    HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
+    if (int rc = upload_scene_records(ctx, d)) return rc;
     return PTMI_OK;
 }
 
@@ -405,6 +446,35 @@ int snapshots_up_to(ptmi_ctx* ctx, DeviceState& d, SnapshotPlan& plan, uint32_t 
     return PTMI_OK;
 }
 
+// How many launches the library keeps in flight AHEAD of a caller that renders one short call after the other and waits for
+// each (DeviceState::ahead): PTMI_RENDER_AHEAD, default 2, 0 = never.
+int render_ahead_depth()
+{
+    const char* e = std::getenv("PTMI_RENDER_AHEAD");  // (read per call: the tests switch it between contexts)
+    const int v = e ? std::atoi(e) : 2;
+    return v < 0 ? 0 : (v > DeviceState::kStageSets - 1 ? DeviceState::kStageSets - 1 : v);
+}
+
+// Stage set `set` able to hold `iterations` iterations (radiance float4 + one statistics word per path).  Growing it waits
+// for whatever may still use the old arrays.
+int ensure_stage_set(ptmi_ctx* ctx, DeviceState& d, int set, size_t iterations)
+{
+    if (d.stage_cap[set] >= iterations) return PTMI_OK;
+    for (auto it = d.ahead.begin(); it != d.ahead.end();)
+        it = it->set == set ? d.ahead.erase(it) : it + 1;
+    if (d.launch_stream[set]) HIP_TRY(ctx, hipStreamSynchronize(d.launch_stream[set]));
+    HIP_TRY(ctx, hipStreamSynchronize(d.stream));
+    if (d.d_stage[set]) (void)hipFree(d.d_stage[set]);
+    d.d_stage[set] = nullptr;
+    d.stage_cap[set] = 0;
+    d.reuse_after[set] = nullptr;
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, iterations * ctx->npix() * 20));
+    d.d_stage[set] = (float*)p;
+    d.stage_cap[set] = iterations;
+    return PTMI_OK;
+}
+
 // One device's launches for its share of a ptmi_render call, bracketed by an event pair for ptmi_kernel_time.
 int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, uint32_t stride, SnapshotPlan* plan = nullptr)
 {
@@ -414,31 +484,25 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
         if (int rc = fold_events(ctx, d)) return rc;
     const bool megakernel = one_path_per_lane(ctx);
     const bool staged = !megakernel && ctx->cfg.sampler != PTMI_SAMPLER_RANDOM;
-    // alternate launch streams: only where the launch itself neither reads nor writes the accumulators (staged results, no
+    // launch streams of their own: only where the launch itself neither reads nor writes the accumulators (staged results, no
     // adaptive sampling), on the context's own stream, and unless switched off (PTMI_SERIAL_LAUNCHES: developer A/B switch)
     static const bool serial_env = std::getenv("PTMI_SERIAL_LAUNCHES") != nullptr;
     const bool may_overlap = staged && !ctx->cfg.super_sampling && d.stream == d.own_stream && !serial_env;
     const size_t npix = ctx->npix();
+    constexpr uint32_t kShort = 4;  // launches of fewer iterations run beside their neighbours (see below)
+    // Rendering ahead: the call is ONE short launch of a single-device context, nothing but staged results leaves the kernel
+    // (the histograms of very deep paths are atomics inside it), and the caller has not asked for an image per iteration
+    const bool can_run_ahead = may_overlap && render_ahead_depth() > 0 && !plan && n < kShort && ctx->n_dev() == 1 &&
+                               !(d.ds.hist_depths && ctx->cfg.ray_max_depth >= 64);
+    if (!can_run_ahead) d.ahead.clear();  // (their sets are free again once their kernels have ended: reuse_after)
     if (staged) {
-        // staging arrays for the launches: grow on demand, capped by iterations_per_launch
+        // staging arrays: set 0 for the longest launch of this call, every set for a short one; grown on demand
         const size_t want = n < ctx->iterations_per_launch ? n : ctx->iterations_per_launch;
-        if (want > d.stage_iterations) {
-            HIP_TRY(ctx, hipStreamSynchronize(d.stream));
-            for (int i = 0; i < 2; i++) {
-                if (d.launch_stream[i]) HIP_TRY(ctx, hipStreamSynchronize(d.launch_stream[i]));
-                if (d.d_stage[i]) (void)hipFree(d.d_stage[i]);
-                d.d_stage[i] = nullptr;
-                d.stage_busy[i] = false;
-            }
-            d.stage_iterations = 0;
-            for (int i = 0; i < 2; i++) {
-                void* p = nullptr;
-                HIP_TRY(ctx, hipMalloc(&p, want * npix * 20));  // float4 radiance + one statistics word per path
-                d.d_stage[i] = (float*)p;
-            }
-            d.stage_iterations = want;
-        }
-        for (int i = 0; i < 2 && may_overlap; i++) {
+        if (int rc = ensure_stage_set(ctx, d, 0, want)) return rc;
+        if (may_overlap && (n % ctx->iterations_per_launch) != 0 && (n % ctx->iterations_per_launch) < kShort)
+            for (int i = 1; i < DeviceState::kStageSets; i++)
+                if (int rc = ensure_stage_set(ctx, d, i, kShort - 1)) return rc;
+        for (int i = 0; i < DeviceState::kStageSets && may_overlap; i++) {
             if (!d.launch_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&d.launch_stream[i], hipStreamNonBlocking));
             if (!d.rendered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.rendered[i], hipEventDisableTiming));
             if (!d.stage_free[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.stage_free[i], hipEventDisableTiming));
@@ -457,9 +521,33 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     }
     std::string err;
     int rc = PTMI_OK;
-    // Both events on the MAIN stream: [previous launch accumulated, this one accumulated].  With alternating launch streams
+    hipError_t e = hipSuccess;
+    const bool stats_build = (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0;
+    // where the statistics words of a set's launches go: staged per path and counted after the launch, unless there is no
+    // histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
+    auto stats_of = [&](int set) -> uint32_t* {
+        if (!(d.d_stage[set] && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)) return nullptr;
+        return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d.d_stage[set]) + d.stage_cap[set] * npix * 16);
+    };
+    // A SHORT launch on stage set `set`: on the set's own stream, counting into the set's own block - it touches nothing else
+    // of the context, whether a call has asked for it or not.
+    auto launch_on_set = [&](int set, uint32_t f, uint32_t m) {
+        hipStream_t ls = d.launch_stream[set];
+        if (d.reuse_after[set]) e = hipStreamWaitEvent(ls, d.reuse_after[set], 0);
+        if (e == hipSuccess) e = hipMemsetAsync(d.d_set_counters[set], 0, C_COUNT * 8, ls);
+        if (e != hipSuccess) return;
+        DScene on_set = d.ds;
+        on_set.counters = d.d_set_counters[set];
+        rc = KERNELS_OF(ctx, launch_render_wavefront)(on_set, d.d_scene_set[set], f, m, stride, d.d_job_counter + set * 8 * 1024, ctx->stack_levels,
+                                                      stats_build, d.d_stage[set], stats_of(set), ls, &err);
+        if (rc != PTMI_OK) return;
+        e = hipEventRecord(d.rendered[set], ls);
+        d.reuse_after[set] = d.rendered[set];  // (until the main stream adopts it)
+        d.launches_issued++;
+    };
+    // Both events on the MAIN stream: [previous launch accumulated, this one accumulated].  With launch streams of their own
     // the intervals still tile the time line (no double counting of the overlap).
-    hipError_t e = hipEventRecord(ev.first, d.stream);
+    e = hipEventRecord(ev.first, d.stream);
     if (e == hipSuccess) {
         if (megakernel) {
             rc = KERNELS_OF(ctx, launch_render)(d.ds, first, n, stride, d.stream, &err);
@@ -469,31 +557,40 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 // SUPER_SAMPLING: the stop criterion of iteration k reads the accumulators after k-1 => one per launch
                 const uint32_t cap = ctx->cfg.super_sampling ? 1u : ctx->iterations_per_launch;
                 const uint32_t m = n - done < cap ? n - done : cap;
-                // Only SHORT launches alternate streams (measured on MI355X, 1M triangles 1080p: one image per launch 631 -> 657
+                const uint32_t f = first + done * stride;
+                // Only SHORT launches get streams of their own (measured on MI355X, 1M triangles 1080p: one image per launch 631 -> 657
                 // Msamples/s with the overlap; 16 images per launch 763 -> 753: two long persistent launches side by side only
                 // get in each other's way, and their ragged ends are 1 % of their length anyway)
-                const bool overlap = may_overlap && m < 4u;
-                const int set = overlap ? (int)(d.launches_issued & 1u) : 0;
-                hipStream_t ls = overlap ? d.launch_stream[set] : d.stream;
-                float* stage = staged ? d.d_stage[set] : nullptr;
-                // histograms: staged per path and counted after the launch, unless there is no staging (RANDOM sampler),
-                // no histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
-                uint32_t* stage_stats = nullptr;
-                if (stage && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)
-                    stage_stats = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + d.stage_iterations * npix * 16);
-                if (may_overlap && d.stage_busy[set]) e = hipStreamWaitEvent(ls, d.stage_free[set], 0);
-                if (e != hipSuccess) break;
-                rc = KERNELS_OF(ctx, launch_render_wavefront)(d.ds, d.d_scene, first + done * stride, m, stride, d.d_job_counter + set * 8 * 1024,
-                                             ctx->stack_levels, (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0, stage,
-                                             stage_stats, ls, &err);
-                if (rc != PTMI_OK) break;
-                if (overlap) {
-                    e = hipEventRecord(d.rendered[set], ls);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(d.stream, d.rendered[set], 0);
+                const bool on_own_stream = may_overlap && m < kShort;
+                int set = 0;
+                if (on_own_stream) {
+                    // a launch that ran ahead of this call?  (the oldest first; anything else the caller did not come back for)
+                    bool found = false;
+                    while (can_run_ahead && !d.ahead.empty() && !found) {
+                        const DeviceState::Ahead a = d.ahead.front();
+                        d.ahead.pop_front();
+                        found = a.first == f && a.n == m && a.stride == stride;
+                        set = a.set;
+                    }
+                    if (!found) {
+                        set = (int)(d.next_set++ % DeviceState::kStageSets);
+                        launch_on_set(set, f, m);
+                        if (rc != PTMI_OK || e != hipSuccess) break;
+                    }
+                    e = hipStreamWaitEvent(d.stream, d.rendered[set], 0);
                     if (e != hipSuccess) break;
+                } else {
+                    if (d.reuse_after[0]) e = hipStreamWaitEvent(d.stream, d.reuse_after[0], 0);  // (a short launch nobody adopted)
+                    if (e != hipSuccess) break;
+                    rc = KERNELS_OF(ctx, launch_render_wavefront)(d.ds, d.d_scene, f, m, stride, d.d_job_counter, ctx->stack_levels, stats_build,
+                                                                  staged ? d.d_stage[0] : nullptr, staged ? stats_of(0) : nullptr, d.stream, &err);
+                    if (rc != PTMI_OK) break;
+                    d.launches_issued++;
                 }
+                float* const stage = staged ? d.d_stage[set] : nullptr;
+                uint32_t* const stage_stats = staged ? stats_of(set) : nullptr;
                 if (!plan) {
-                    rc = KERNELS_OF(ctx, launch_accumulate_staged)(d.ds, first + done * stride, m, stage, stage_stats, true, d.stream, &err);
+                    rc = KERNELS_OF(ctx, launch_accumulate_staged)(d.ds, f, m, stage, stage_stats, true, d.stream, &err);
                 } else {
                     // one accumulation per iteration, each followed by the snapshots of the global iterations up to it
                     for (uint32_t j = 0; j < m && rc == PTMI_OK; j++) {
@@ -510,12 +607,26 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     if (rc != PTMI_OK && err.empty()) err = ctx->err;
                 }
                 if (rc != PTMI_OK) break;
-                if (may_overlap) {  // (also behind a launch on the main stream: a later short launch may take this set)
+                if (on_own_stream) rc = launch_add_counters(d.d_counters, d.d_set_counters[set], C_COUNT, d.stream, &err);
+                if (rc != PTMI_OK) break;
+                if (staged && may_overlap) {  // (also behind a launch on the main stream: a later short launch may take set 0)
                     e = hipEventRecord(d.stage_free[set], d.stream);
-                    d.stage_busy[set] = true;
+                    d.reuse_after[set] = d.stage_free[set];
                 }
-                d.launches_issued++;
                 done += m;
+            }
+            // keep the next launches of a caller that comes back for one short call after the other in flight
+            const bool continues = d.have_last && d.last_n == n && d.last_stride == stride &&
+                                   (uint64_t)d.last_first + (uint64_t)n * stride == (uint64_t)first;
+            if (can_run_ahead && continues && rc == PTMI_OK && e == hipSuccess) {
+                uint64_t next = d.ahead.empty() ? (uint64_t)first + (uint64_t)n * stride : (uint64_t)d.ahead.back().first + (uint64_t)n * stride;
+                while ((int)d.ahead.size() < render_ahead_depth() && next + (uint64_t)(n - 1) * stride <= 0xFFFFFFFFull &&
+                       rc == PTMI_OK && e == hipSuccess) {
+                    const int set = (int)(d.next_set++ % DeviceState::kStageSets);
+                    launch_on_set(set, (uint32_t)next, n);
+                    if (rc == PTMI_OK && e == hipSuccess) d.ahead.push_back({(uint32_t)next, n, stride, set});
+                    next += (uint64_t)n * stride;
+                }
             }
         }
         if (e == hipSuccess && rc == PTMI_OK && plan) rc = snapshots_up_to(ctx, d, *plan, plan->n);  // images after its last own one
@@ -527,6 +638,8 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
         return fail(ctx, PTMI_ERR_HIP, std::string("launch sequencing: ") + hipGetErrorString(e));
     }
     d.pending_events.push_back(ev);
+    d.have_last = true;
+    d.last_first = first; d.last_n = n; d.last_stride = stride;
     return PTMI_OK;
 }
 
@@ -1267,7 +1380,7 @@ int ptmi_bind_accumulators(ptmi_ctx* ctx, void* d_color, void* d_count)
     d.ds.image_color = d_color ? (float*)d_color : d.d_color;
     d.ds.image_ray_nb = d_count ? (float*)d_count : d.d_count;
     ctx->accum_bound = d_color != nullptr;
-    HIP_TRY(ctx, hipMemcpy(d.d_scene, &d.ds, sizeof(DScene), hipMemcpyHostToDevice));
+    if (int rc = upload_scene_records(ctx, d)) return rc;
     return PTMI_OK;
 }
 
@@ -1288,7 +1401,7 @@ void ptmi_release(ptmi_ctx* ctx)
         for (uint32_t k = 0; k < PTMI_MAX_SNAPSHOT_SLOTS; k++)
             if (d.snapshot_ready[k]) (void)hipEventDestroy(d.snapshot_ready[k]);
         if (d.peer_copied) (void)hipEventDestroy(d.peer_copied);
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < DeviceState::kStageSets; i++) {
             if (d.rendered[i]) (void)hipEventDestroy(d.rendered[i]);
             if (d.stage_free[i]) (void)hipEventDestroy(d.stage_free[i]);
             if (d.launch_stream[i]) (void)hipStreamDestroy(d.launch_stream[i]);

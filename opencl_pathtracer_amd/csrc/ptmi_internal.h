@@ -186,6 +186,8 @@ int launch_display_bgr(const float* image_color, const float* image_ray_nb, uint
 // display.hip: out[i] = ((parts[0][i] + parts[1][i]) + parts[2][i]) + ...  in this fixed order (the accumulators of the devices
 // that shared a render, summed on the first one: ptmi_read_image / ptmi_read_snapshot); n_parts <= PTMI_MAX_DEVICES
 int launch_sum_images(float* out, const float* const* parts, uint32_t n_parts, size_t n_floats, void* stream, std::string* err);
+// dst[i] += src[i], i < n <= 64 (display.hip): a stage set's counter block into the context's
+int launch_add_counters(unsigned long long* dst, const unsigned long long* src, uint32_t n, void* stream, std::string* err);
 
 // iterations one wavefront launch may cover (bounds the staging array: 16 B x pixels x this)
 #ifndef PTMI_MAX_ITERATIONS_PER_LAUNCH

@@ -21,38 +21,21 @@ SPILL_BUDGET = {"general": 72, "plain": 8}
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("arithmetic", [0, 1])
-def test_wavefront_kernel_keeps_five_waves_per_simd(arithmetic, tmp_path):
-    csrc = os.path.join(ROOT, "opencl_pathtracer_amd", "csrc")
-    ns = "_ZN11ptmi_dev_da" if arithmetic else "_ZN8ptmi_dev"
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-           f"-DPTMI_DEFAULT_ARITHMETIC={arithmetic}",
-           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "--cuda-device-only", "-S",
-           os.path.join(csrc, "kernel_wavefront.hip"), "-o", str(tmp_path / "wf.s"), "-Rpass-analysis=kernel-resource-usage"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    # remarks come in blocks: "Function Name: <mangled>" followed by the figures of that function
-    blocks = re.split(r"Function Name: ", r.stderr)[1:]
-    # the two production specialisations: precomputed triangles, general / plain shading
-    main = [b for b in blocks if b.startswith(ns + "23render_wavefront_kernelILb0ELb1ELb0ELb")]
-    assert len(main) == 2, [b[:60] for b in blocks]
-    for block in main:
-        figures = {k: int(v) for k, v in re.findall(r"remark: [^\n]*?\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", block)}
-        assert figures["VGPRs"] <= 96, figures
-        assert figures["Occupancy"] >= 5, figures
-        kind = "plain" if "ILb0ELb1ELb0ELb1E" in block[:70] else "general"
-        assert figures["VGPRs Spill"] <= SPILL_BUDGET[kind], (kind, figures)
-    # the traversal loop (the depth-2 loops of every specialisation) must not touch scratch in the production specialisations
-    # (no scheduler statistics, no adaptive sampling): spills belong to the path-logic pass.  The instrumented ones
-    # (<true, ...>: --scheduler-stats, SUPER_SAMPLING) carry more state and may reload a few words.
-    depth2, name, hot_scratch = False, None, {}
-    for line in open(tmp_path / "wf.s"):
-        m = re.match(r"(" + ns + r"23render_wavefront_kernelILb[01]ELb[01]ELb[01]ELb[01]E)\w*:", line)
-        if m:
-            name, depth2 = m.group(1), False
-        elif re.match(r"(\.LBB|; %bb\.)", line):
-            depth2 = "Depth=2" in line
-        elif depth2 and "scratch_" in line and name is not None:
-            hot_scratch[name] = hot_scratch.get(name, 0) + 1
-    production = {k: v for k, v in hot_scratch.items() if "ILb0E" in k}
-    assert not production, f"scratch instructions inside a traversal loop: {production}"
-    assert all(v <= 6 for v in hot_scratch.values()), hot_scratch  # (instrumented builds only: statistics + invariant checks, SUPER_SAMPLING)
+def test_wavefront_kernel_keeps_five_waves_per_simd(arithmetic):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import resources
+    res = resources(ROOT, arithmetic)  # key = STATS PRE SS PLAIN NANSAFE as five 0/1 digits
+    # the production specialisations: no scheduler statistics, no adaptive sampling; precomputed triangles or not, general /
+    # plain shading, with / without the NaN check of scenes whose records yield NaN distances
+    production = {k: v for k, v in res.items() if k[0] == "0" and k[2] == "0"}
+    assert {"01000", "01010", "01001", "01011", "00000", "00001"} <= set(production), sorted(res)
+    for key, figures in production.items():
+        assert figures["VGPRs"] <= 96 and figures["Occupancy"] >= 5, (key, figures)
+        nan_safe = key[4] == "1"  # (scenes whose records yield NaN distances: a few more live values, rare scenes - a little slack)
+        assert figures["VGPRs Spill"] <= SPILL_BUDGET["plain" if key[3] == "1" else "general"] + (4 if nan_safe else 0), (key, figures)
+        # the traversal loop (the depth-2 blocks) must not touch scratch: spills belong to the path-logic pass
+        assert figures["loop scratch"] <= (2 if nan_safe else 0), (key, figures)
+    # the instrumented ones (<true, ...>: --scheduler-stats, SUPER_SAMPLING) carry more state and may reload a few words
+    for key, figures in res.items():
+        assert figures["VGPRs"] <= 96 and figures["Occupancy"] >= 5 and figures["loop scratch"] <= 8, (key, figures)

@@ -18,6 +18,7 @@ build_one() {
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/display.hip -o $obj/display.o &
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/ptmi_api.cpp -o $obj/ptmi_api.o &
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/bvh_build.cpp -o $obj/bvh_build.o &
+    /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/scene_layout.cpp -o $obj/scene_layout.o &
     wait; } 2> $OUT/build_$name.log
   /opt/rocm/bin/hipcc $FLAGS -shared $obj/*.o -o $OUT/libptmi_$name.so 2>> $OUT/build_$name.log && echo "built $name" || { echo "$name: BUILD FAILED"; tail -5 $OUT/build_$name.log; }
   rm -rf $obj

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Rate of the wavefront kernel's NANSAFE instantiation on scenes whose records yield NaN distances (zero-area triangles as
+the importer emits them), next to the same seeds without those records and to the one-path-per-lane kernel that rendered such
+scenes as a whole before round 4 (PTMI_LITERAL_KERNEL=1).  Run on the GPU box:
+    python tools/nansafe_rate.py > gpurun_out/r04_nansafe_rate.json
+VERDICT r03 item 4: done = the hostile scene renders on the wavefront kernel at >= 0.9 x the clean scene's rate."""
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import opencl_pathtracer_amd as pt  # noqa: E402
+from opencl_pathtracer_amd import backend, scenes  # noqa: E402
+from opencl_pathtracer_amd import structs as S  # noqa: E402
+
+W, H, D, SPP, REPS = 1920, 1080, 10, 16, 3
+DA = backend.FLAG_DEFAULT_ARITHMETIC
+
+
+def rate(sc, flags, env=None, spp=None, reps=None):
+    spp, reps = spp or SPP, reps or REPS
+    print(f"  rate: {sc.name} {len(sc.triangulation)} triangles {env or ''} ...", file=sys.stderr, flush=True)
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    try:
+        be = backend.Backend().setup_context(W, H, D, sc.lightsSize, S.JITTERED, flags=flags)
+        be.initialize_memory(sc)
+        be.render(1000, spp)
+        be.synchronize()
+        c0 = be.counters()
+        t0 = time.perf_counter()
+        for r in range(reps):
+            be.render(r * spp, spp)
+            be.synchronize()
+            print(f"    {r + 1}/{reps} after {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+        dt = time.perf_counter() - t0
+        c1 = be.counters()
+        st = be.scheduler_stats()
+        why = be.literal_kernel_reason()
+        be.release()
+    finally:
+        for k in (env or {}):
+            del os.environ[k]
+    seg = c1["segments"] - c0["segments"]
+    return {"Msamples/s": seg / dt / 1e6, "Mpaths/s": (c1["paths"] - c0["paths"]) / dt / 1e6, "paths_retraced": st["paths_retraced"],
+            "paths": c1["paths"], "iterations_per_launch": spp, "launches": reps,
+            "literal_kernel_reason": why.decode() if isinstance(why, bytes) else why}
+
+
+import copy  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+
+def without_bad_records(sc):
+    """The clean twin of a hostile scene: the same scene minus the triangles that make the library choose the NANSAFE
+    instantiation (non-finite or astronomically large records, zero-area triangles), with a tree of its own."""
+    t = sc.triangulation
+    ok = np.ones(len(t), bool)
+    for f in ("S1", "S2", "S3"):
+        ok &= np.isfinite(t[f]).all(axis=1) & (np.abs(t[f]) <= 2097152.0).all(axis=1)
+    for f in ("N", "N1", "N2", "N3"):
+        ok &= np.isfinite(t[f]).all(axis=1) & (np.abs(t[f]) <= 16.0).all(axis=1)
+    u, v = (t["S2"] - t["S1"]).astype(np.float64), (t["S3"] - t["S1"]).astype(np.float64)
+    uv, uu, vv = (u * v).sum(1), (u * u).sum(1), (v * v).sum(1)
+    ok &= np.float32(uv * uv - uu * vv) != 0
+    twin = copy.copy(sc)
+    twin.triangulation = t[ok].copy()
+    twin.triangulation["id"] = np.arange(ok.sum(), dtype=np.uint32)
+    twin.bvh = None
+    return pt.bvh_create(twin), int((~ok).sum())
+
+
+def with_zero_area_triangles(sc, k, seed=5):
+    """`k` zero-area triangles as the importer emits them (three collinear vertices: N = 0/0, MayaImporter.cpp:943-1047 via
+    scenes.triangle_create) scattered through the scene's volume: what a real imported mesh brings along."""
+    rs = np.random.RandomState(seed)
+    lo, hi = sc.triangulation["S1"][:, :3].min(0), sc.triangulation["S1"][:, :3].max(0)
+    # (coordinates with few mantissa bits: a, a + e, a + 2e are then EXACTLY collinear in float, so the cross product is 0)
+    a = (np.round(rs.uniform(lo * 0.8, hi * 0.8, (k, 3)) * 16) / 16).astype(np.float32)
+    e = (np.round(rs.uniform(0.01, 0.06, (k, 3)) * 256) / 256).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bad = scenes.triangle_create(a, a + e, a + 2 * e, mat_pos=0)
+    out = copy.copy(sc)
+    out.triangulation = scenes._concat_tris([sc.triangulation, bad])
+    out.bvh = None
+    return pt.bvh_create(out)
+
+
+def entry(name, clean, hostile, removed=None):
+    e = {"triangles": int(len(hostile.triangulation)),
+         "clean_wavefront": rate(clean, DA),
+         "hostile_wavefront_nansafe": rate(hostile, DA),
+         "hostile_one_path_per_lane": rate(hostile, DA, {"PTMI_LITERAL_KERNEL": "1"}, spp=2, reps=2)}
+    if removed is not None:
+        e["bad_records"] = removed
+    e["nansafe_over_clean"] = e["hostile_wavefront_nansafe"]["Msamples/s"] / e["clean_wavefront"]["Msamples/s"]
+    e["nansafe_over_one_path_per_lane"] = e["hostile_wavefront_nansafe"]["Msamples/s"] / e["hostile_one_path_per_lane"]["Msamples/s"]
+    e["share_of_paths_retraced"] = e["hostile_wavefront_nansafe"]["paths_retraced"] / e["hostile_wavefront_nansafe"]["paths"]
+    out["scenes"][name] = e
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_nansafe_rate_partial.json"), "w"), indent=1)  # (a killed run keeps what it has)
+    return e
+
+
+out = {"config": f"{W}x{H}, depth {D}, {SPP} iterations per launch x {REPS}, default arithmetic, JITTERED",
+       "note": "clean = the same scene without its bad records (fuzz: scenes.fuzz_scene hostile set removed; tris1m: before the "
+               "zero-area triangles were added).  A path that meets a NaN distance is expensive by itself - nothing is 'too far' "
+               "for it any more, so it walks most of the tree (the reference's kernel does the same) - so a scene where 7 % of the "
+               "paths do (fuzz3h) cannot run at its clean twin's rate; a mesh with a few degenerate triangles does.", "scenes": {}}
+for seed in (3, 7):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hostile = pt.bvh_create(scenes.build(f"fuzz{seed}h_l1", W, H))
+        clean, removed = without_bad_records(hostile)
+    entry(f"fuzz{seed}h_l1", clean, hostile, removed)
+base = pt.bvh_create(scenes.build("tris1m", W, H))
+for k in (1, 100):
+    entry(f"tris1m + {k} zero-area triangle(s)", base, with_zero_area_triangles(base, k), k)
+print(json.dumps(out, indent=1))
