@@ -42,14 +42,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
-# What the 256 L1s (TCP) of the chip take, measured with tools/microbench on MI355X (profiles/r01_ab_late_round.txt),
-# independent of occupancy from 2 to 8 waves per SIMD:
-#   accesses: random 64-byte records read with four dwordx4 loads per lane, set resident in the L2s: 214.5 G records/s x 4
-#   line fills: random 32-byte records (one new line per record): 258 G/s from the L2s, 58 G/s from the Infinity Cache
-L1_ACCESS_RATE = 4 * 214.5e9
-L1_ACCESSES_PER_RECORD = 3.14  # what this kernel needs per 64-byte record (profiles/r03_pmc_tris1m_default.json: a rejected triangle reads half of its record)
-L1_FILL_RATE_L2 = 258.2e9
+# What the 256 L1s (TCP) of the chip take for this kernel's kind of load - every lane reads ONE 64-byte record of its own with
+# dwordx4 loads - comes from a committed record: profiles/r04_l1_gather_microbench.json (tools/microbench/l1_gather.hip run by
+# tools/l1_ceiling.sh on MI355X, with the L1's own counters of the same launches beside every rate).  Its `kernel_mix` regime is
+# the kernel's own by its PMC profile: 600 of 1000 records cost a line fill, served by the L2s, 3.14 accesses per record; the
+# counters show that regime access-bound (it reaches 94 % of the all-hits rate; every record a NEW line reaches 73 %).
+L1_ACCESSES_PER_RECORD = 3.14  # what this kernel needs per 64-byte record (PMC: a rejected triangle reads half of its record)
+L1_FILL_RATE_L2 = 258.2e9      # line fills from the L2s / the Infinity Cache (tools/microbench/record_size, profiles/r01_ab_late_round.txt)
 L1_FILL_RATE_MALL = 58.1e9
+
+
+def l1_ceiling():
+    """(accesses per second, where the figure comes from)"""
+    path = os.path.join(ROOT, "profiles", "r04_l1_gather_microbench.json")
+    try:
+        rec = json.load(open(path))
+        c = rec["ceiling"]
+        return c["kernel_mix_G_per_s"] * 1e9, {"source": "profiles/r04_l1_gather_microbench.json (tools/l1_ceiling.sh)",
+                                               "regime": "kernel_mix: 600 of 1000 records cost a line fill from the L2s, 3.14 accesses per record",
+                                               "pure_access_rate_G_per_s": c["pure_access_rate_G_per_s"],
+                                               "every_record_a_new_line_from_l2_G_per_s": c.get("every_record_a_new_line_from_l2_G_per_s")}
+    except (OSError, KeyError, ValueError):
+        # (the record is part of the repository; without it the round-1 figure: 214.5 G records/s x 4 on a 2 MB set)
+        return 4 * 214.5e9, {"source": "profiles/r01_ab_late_round.txt (fallback: profiles/r04_l1_gather_microbench.json not found)"}
+
+
+L1_ACCESS_RATE, L1_CEILING_SOURCE = l1_ceiling()
 
 
 def algorithmic_bytes(c, n_pixels, n_flush, textured_hits=0):
@@ -166,6 +184,9 @@ def main():
         scratch = torch.zeros_like(fb.buffer)
         dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
         del scratch
+    if rank == 0 and args.warmup > 0:
+        # ... and the readback path (torch sets up its device-to-host copy on first use: ~7 ms, half of a two-launch Cornell region)
+        host_image.copy_(fb.buffer, non_blocking=True)
     torch.cuda.synchronize(device)
     be.kernel_time()  # drop warm-up launches
     c0 = be.counters()
@@ -240,7 +261,9 @@ def main():
             # 64-byte record gathers against what the chip's L1s deliver for that access pattern (tools/microbench/record_fetch)
             rate = records_per_launch / avg_launch_s * L1_ACCESSES_PER_RECORD
             roof.update({"bound": "l1_accesses (estimated)", "achieved": rate / 1e9, "peak": L1_ACCESS_RATE / 1e9, "unit": "G accesses/s",
-                         "frac": rate / L1_ACCESS_RATE,
+                         "frac": rate / L1_ACCESS_RATE, "ceiling": L1_CEILING_SOURCE,
+                         "pmc_fallback": "LOUD: no PMC passes of this kernel source are committed for this workload - the counter-backed "
+                                         "table (binding, traffic, hbm_measured) is missing from this line; run tools/profile_round.sh",
                          "note": "no committed PMC passes match this kernel source + workload + arithmetic (profiles/r03_pmc_*.json): the L1 "
                                  f"access rate is ESTIMATED as records fetched x {L1_ACCESSES_PER_RECORD} accesses per record (measured for this "
                                  "kernel on the 1M-triangle workload) against the gather ceiling of tools/microbench/record_fetch; run "
@@ -260,6 +283,12 @@ def main():
                        "spp_per_step": B if strong else B * world, "spp_per_step_per_gpu": B / world if strong else B,
                        "spp_total": args.steps * B * (1 if strong else world),
                        "parallelism": f"spp-shard x{world}" if world > 1 else "single GPU",
+                       # what the collective of the timed region saw (for the driver's SCALE record): ranks of the process
+                       # group the reduce ran in, its backend, and the devices the ranks hold
+                       "collective": {"ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                                      "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
+                                      "op": "reduce(sum) of float[5*W*H] onto rank 0" if world > 1 else None,
+                                      "rank0_device": torch.cuda.get_device_name(device)},
                        "timed_region": "launches + RCCL reduce + one framebuffer readback to rank 0 (pinned host memory)",
                        "scene_build_s": round(t_scene, 2)},
             "Mpaths/s": total["paths"] / elapsed / 1e6,
@@ -396,7 +425,8 @@ def binding_ceilings(pmc, launch_s, records_per_launch):
             # line fills, the latter for this scene's split between fills from the L2s and from the Infinity Cache / HBM
             acc, fills = v("TCP_TOTAL_CACHE_ACCESSES_sum"), v("TCP_TCC_READ_REQ_sum")
             binding["l1_accesses"] = {"achieved": acc / launch_s / 1e9, "peak": L1_ACCESS_RATE / 1e9, "unit": "G accesses/s",
-                                      "frac": acc / launch_s / L1_ACCESS_RATE, "per_record": acc / records_per_launch}
+                                      "frac": acc / launch_s / L1_ACCESS_RATE, "per_record": acc / records_per_launch,
+                                      "fills_per_access": fills / acc, "ceiling": L1_CEILING_SOURCE}
             t_min = fills * (hit / L1_FILL_RATE_L2 + (1.0 - hit) / L1_FILL_RATE_MALL)
             binding["l1_line_fills"] = {"achieved": fills / launch_s / 1e9, "peak": fills / t_min / 1e9, "unit": "G lines/s",
                                         "frac": t_min / launch_s, "per_record": fills / records_per_launch}

@@ -253,6 +253,13 @@ int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out);
  * super_sampling).  The string lives until the next ptmi_initialize_memory / ptmi_release. */
 const char* ptmi_literal_kernel_reason(const ptmi_ctx* ctx);
 
+/* How a multi-device context sums its devices' partial images (for records and scaling logs): *rccl_state = 1 when the last sum
+ * went through ncclReduce (PTMI_REDUCE=rccl), 0 when the collective has not been tried, -1 when it is unavailable or was refused
+ * (peer copies + the add kernel in device order: the default); *n_communicators = the communicators ncclCommInitAll returned for
+ * this context (= the device count when the collective is in use, else 0); *nccl_version = ncclGetVersion's code (0: library not
+ * loaded).  Any pointer may be NULL. */
+int ptmi_reduce_path(const ptmi_ctx* ctx, int* rccl_state, int* n_communicators, int* nccl_version);
+
 /* Device time of the integrator kernel launches issued by ptmi_render since the
  * last call, measured with HIP events on the context's stream.  Synchronises. */
 int ptmi_kernel_time(ptmi_ctx* ctx, double* total_ms, uint32_t* n_launches);

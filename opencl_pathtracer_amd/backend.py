@@ -97,7 +97,7 @@ FLAG_SOURCE_SEED = 32  # non-parity mode: seed 1 (as the source text reads) wher
 # every symbol include/ptmi.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = ["ptmi_setup_context", "ptmi_initialize_memory", "ptmi_render", "ptmi_synchronize", "ptmi_read_image",
                "ptmi_write_image", "ptmi_pin_host_buffer", "ptmi_unpin_host_buffer", "ptmi_snapshot", "ptmi_render_snapshots", "ptmi_read_snapshot", "ptmi_write_variance", "ptmi_read_display", "ptmi_read_statistics", "ptmi_clear", "ptmi_release", "ptmi_get_counters", "ptmi_get_scheduler_stats", "ptmi_get_invariant_checks", "ptmi_literal_kernel_reason", "ptmi_validate_scene",
-               "ptmi_kernel_time",
+               "ptmi_kernel_time", "ptmi_reduce_path",
                "ptmi_set_stream", "ptmi_device_accumulators", "ptmi_bind_accumulators", "ptmi_read_variance",
                "ptmi_device_variance", "ptmi_last_error",
                "ptmi_abi_version", "ptmi_device_count", "ptmi_device_share", "ptmi_bvh_create"]
@@ -140,6 +140,7 @@ def load_library():
     lib.ptmi_literal_kernel_reason.argtypes = [vp]
     lib.ptmi_literal_kernel_reason.restype = C.c_char_p
     lib.ptmi_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u32)]
+    lib.ptmi_reduce_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.ptmi_set_stream.argtypes = [vp, vp]
     lib.ptmi_device_accumulators.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.ptmi_bind_accumulators.argtypes = [vp, vp, vp]
@@ -350,6 +351,12 @@ class Backend:
         triangle test yields NaN distances: ptmi.h)."""
         r = self._lib.ptmi_literal_kernel_reason(self._ctx)
         return r.decode() if r else None
+
+    def reduce_path(self):
+        """How a multi-device context sums its partial images: dict(rccl_state, communicators, nccl_version) (ptmi_reduce_path)"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.ptmi_reduce_path(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return {"rccl_state": a.value, "communicators": b.value, "nccl_version": c.value}
 
     def kernel_time(self):
         """(total_ms, launches) of the integrator kernel since the last call (HIP events on its stream)."""

@@ -128,6 +128,17 @@ static_assert(!kLeafPass || kHitWords == 4, "leaf passes write the 4-word closes
 // the waiting triangles are kLeafRatio times as many as the lanes left to take node steps
 constexpr int kLeafLanes = PTMI_WF_LEAF_LANES, kLeafRatio = PTMI_WF_LEAF_RATIO;
 constexpr int kLeafPassWords = kLeafPass ? 4 * kWfBlock : 0;  // LDS: one 64-bit key per lane + 64 items of 8 bytes per wave
+#ifndef PTMI_WF_TOS
+// The top entry of a lane's traversal stack ALSO in a register (round 4): a pop takes the register and the LDS read that refills
+// it is not needed before the lane's NEXT pop, instead of an LDS round trip on the critical path of every node step.
+// 0: never, 1: every instantiation, 2: the general shading instantiations only.  Measured on MI355X, same box, two rounds,
+// Msamples/s (1M triangles plain / 1M triangles general shading forced / Cornell box 1080p d8 plain / material mix 4K d16 general /
+// configs[4] stand-in 4K d16 general, four workgroups per CU / 4M triangles plain, four workgroups per CU):
+//   0: 973.9 / 916.2 / 7197 / 2511 / 1161 / 517.1      1: 965.7 / 943.1 / 7215 / 2658 / 1211 / 510.7      2: 973.6 / 941.8 / 7263 / 2659 / 1214 / 516.9
+// The general instantiations gain 3-6 % (their spilled registers also fall from 67 to 30: the allocator's doing), the plain one
+// loses 0.8 %: hence 2.
+#define PTMI_WF_TOS 2
+#endif
 
 // Scene fields by value (SGPRs): what the traversal trips and EVERY path-logic trip need.  The rarely used
 // rest of DScene (sky: only when a path escapes; histogram / RANDOM-sampler / SUPER_SAMPLING buffers; counters)
@@ -210,6 +221,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
     DWarm sc = sc_arg;
     if (PLAIN) { sc.sampler = PTMI_SAMPLER_JITTERED; sc.russian_roulette = 0; sc.n_lights = 1; }  // ... and ONE light
     constexpr bool kOneLight = PLAIN;  // (nothing gathered across shadow queries, no light index: five registers fewer per lane)
+    constexpr bool kTos = PTMI_WF_TOS == 1 || (PTMI_WF_TOS == 2 && !PLAIN);
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_mem[];
     __shared__ unsigned long long block_counters[C_COUNT];
 
@@ -265,6 +277,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
     uint32_t cur = REF_IDLE, tri_i = 0, tri_end = 0;
     uint32_t dir_signs = 0;  // bit k: direction component k > 0 (which child of a node cut along k is the near one)
     uint32_t* sp = stack_floor;  // the top entry (the sentinel when the stack is empty)
+    uint32_t tos = REF_NONE;     // kTos: ... and its value (PTMI_WF_TOS); invariant tos == *sp
     // the point of the closest hit, as path logic needs it when a query has finished
     auto load_hit_point = [&]() {
         if (kHitWords == 8)
@@ -368,6 +381,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
     // the range is free.
     auto start_query = [&]() {
         cur = sc.root_ref; sp = stack_floor; tri_i = tri_end = 0;
+        if (kTos) tos = REF_NONE;
         // "found" of THIS query (a shadow query leaves the rest of the closest hit's record alone)
         if (kHitWords == 8) hit_mem[7 * kWfBlock] = 0;
         else if (shadow) atomicAnd(&hit_mem[kWordTri * kWfBlock], ~kHitFound);
@@ -476,6 +490,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                 reflection = 0; p_bbx = 0; p_tri = 0;
                 hit_mem[kWordTri * kWfBlock] = 0;
                 cur = REF_NONE; tri_i = tri_end = 0; sp = stack_floor;
+                if (kTos) tos = REF_NONE;
                 job_counter[1] = 1u;
             } else
             if (!shadow) {
@@ -490,9 +505,10 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
             }
             if (tri_i >= tri_end && cur != REF_NONE && (cur & REF_LEAF)) {
                 decode_leaf(sc, cur, tri_i, tri_end);
-                cur = *sp;
+                cur = kTos ? tos : *sp;
                 uint32_t* const under = sp - kWfBlock;
                 sp = under < stack_floor ? stack_floor : under;
+                if (kTos) tos = *sp;
             }
         }
     };
@@ -519,6 +535,30 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
         p_bbx += 2;
         // (every choice as a select on the two hit masks themselves: combined into new booleans first - both, neither - the
         // compiler builds them as 0 / 1 integers in vector registers: seven instructions more per step)
+        if (kTos) {
+            const uint32_t far_ref = fwd ? ref2 : ref1;
+            sp[kWfBlock] = far_ref;
+            uint32_t* const pushed = sp + kWfBlock;
+            const uint32_t child = fwd ? (h1 ? ref1 : ref2) : (h2 ? ref2 : ref1);  // near child if it was hit, else the far one
+            // both hit: the far child becomes the top; one hit: nothing moves; none: the top is the next node and the entry
+            // under it becomes the top - read from LDS, but needed only when this lane pops the next time
+            cur = h1 ? child : (h2 ? child : tos);
+            tos = h1 ? (h2 ? far_ref : tos) : tos;
+            sp = h1 ? (h2 ? pushed : sp) : sp;
+            if (!(h1 | h2)) {
+                uint32_t* const below = sp - kWfBlock;
+                sp = below < stack_floor ? stack_floor : below;
+                tos = *sp;
+            }
+            if (cur != REF_NONE && (cur & REF_LEAF)) {  // (the triangle range of a lane that takes node steps is free)
+                decode_leaf(sc, cur, tri_i, tri_end);
+                cur = tos;
+                uint32_t* const under = sp - kWfBlock;
+                sp = under < stack_floor ? stack_floor : under;
+                tos = *sp;
+            }
+            return;
+        }
         sp[kWfBlock] = fwd ? ref2 : ref1;
         uint32_t* const pushed = sp + kWfBlock;
         sp = h1 ? (h2 ? pushed : sp) : sp;

@@ -1062,6 +1062,19 @@ int ptmi_render_snapshots(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_it
     return PTMI_OK;
 }
 
+int ptmi_reduce_path(const ptmi_ctx* ctx, int* rccl_state, int* n_communicators, int* nccl_version)
+{
+    if (!ctx) return PTMI_ERR_INVALID_ARGUMENT;
+    if (rccl_state) *rccl_state = ctx->rccl_state;
+    if (n_communicators) {
+        int n = 0;
+        for (void* c : ctx->rccl_comms) n += c != nullptr;
+        *n_communicators = n;
+    }
+    if (nccl_version) *nccl_version = ctx->rccl_state != 0 ? rccl_api().version : 0;  // (never loads the library by itself)
+    return PTMI_OK;
+}
+
 const char* ptmi_literal_kernel_reason(const ptmi_ctx* ctx)
 {
     return ctx && ctx->have_scene && !ctx->literal_kernel_reason.empty() ? ctx->literal_kernel_reason.c_str() : nullptr;

@@ -91,6 +91,21 @@ def with_zero_area_triangles(sc, k, seed=5):
     return pt.bvh_create(out)
 
 
+def reference_rate(sc):
+    """The reference's own kernel (oracle/_ref: unmodified source, its own build options) on the same scene, one iteration after
+    a warm-up launch: what the paths that meet a NaN record cost THERE."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    case = f"tris1m_{W}x{H}_d{D}"  # (the code object is specialised on sampler, size, depth and light count only)
+    if not O.have_ref_kernel(case) or sc.lightsSize != 1:
+        return None
+    print(f"  reference kernel: {sc.name} ...", file=sys.stderr, flush=True)
+    O.ref_gpu_render(case, sc, W, H, D, 1, first_iteration=7)
+    _, _, (dep, _, _), ms = O.ref_gpu_render(case, sc, W, H, D, 1)
+    seg = int(sum(min(k + 1, D) * int(n) for k, n in enumerate(dep)))  # (upper bound: a path that ends on a hit at depth k made k queries)
+    return {"Mpaths/s": W * H / ms / 1e3, "kernel_ms_per_iteration": ms}
+
+
 def entry(name, clean, hostile, removed=None):
     e = {"triangles": int(len(hostile.triangulation)),
          "clean_wavefront": rate(clean, DA),
@@ -98,6 +113,10 @@ def entry(name, clean, hostile, removed=None):
          "hostile_one_path_per_lane": rate(hostile, DA, {"PTMI_LITERAL_KERNEL": "1"}, spp=2, reps=2)}
     if removed is not None:
         e["bad_records"] = removed
+    ref = reference_rate(hostile)
+    if ref:
+        e["reference_kernel_on_the_hostile_scene"] = ref
+        e["nansafe_over_reference_kernel"] = e["hostile_wavefront_nansafe"]["Mpaths/s"] / ref["Mpaths/s"]
     e["nansafe_over_clean"] = e["hostile_wavefront_nansafe"]["Msamples/s"] / e["clean_wavefront"]["Msamples/s"]
     e["nansafe_over_one_path_per_lane"] = e["hostile_wavefront_nansafe"]["Msamples/s"] / e["hostile_one_path_per_lane"]["Msamples/s"]
     e["share_of_paths_retraced"] = e["hostile_wavefront_nansafe"]["paths_retraced"] / e["hostile_wavefront_nansafe"]["paths"]
