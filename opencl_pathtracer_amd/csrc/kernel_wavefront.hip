@@ -55,6 +55,7 @@
 #include "ptmi_literal_path.hpp"
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 namespace PTMI_DEV_NS {
@@ -173,6 +174,14 @@ constexpr uint32_t kStatDepthBins = 64;
 // payload survives the additions and fused multiply-adds that follow (tools/microbench/nan_payload.hip) -, its counters
 // restart at zero, the launch's job-counter block gets a non-zero word 1, and redo_poisoned_kernel traces the path again.
 constexpr uint32_t kPoisonMarker = 0x7FC0DEADu;
+// The RANDOM sampler stages nothing (its samples land on arbitrary pixels and are added atomically), so a path it gives up is
+// not marked in a staging slot: its slot number goes to a LIST in the launch's job-counter block - word 2 counts, the entries
+// start at word kGiveUpListFirst, behind the queue counters - and bit 31 of the lane's slot word says "this path adds nothing";
+// redo_random_kernel traces the listed paths again and adds them atomically.  A launch that fills the list (7680 paths whose
+// ray is not a number: scenes of NaN records never get here, they run the one-path-per-lane kernel with this sampler) lets the
+// rest keep the ordered minimum, as every such path did before round 4.
+constexpr uint32_t kGivenUp = 0x80000000u, kGiveUpListFirst = (uint32_t)(kQueues * kQueueStride), kGiveUpListCap = 8u * 1024u - kGiveUpListFirst;
+static_assert(kQueues * kQueueStride <= 1024, "the give-up list lies behind the queue counters inside the set's 8 x 1024 dwords");
 __device__ __forceinline__ uint32_t pack_path_statistics(uint32_t depth, uint32_t bbx, uint32_t tri)
 {
     static_assert(PTMI_MAX_INTERSECTION_NUMBER <= 8191, "13-bit fields");
@@ -324,7 +333,8 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
         atomicAdd(&totals[C_BBX], (unsigned long long)p_bbx);
         atomicAdd(&totals[C_TRI], (unsigned long long)p_tri);
         check(p_bbx < PTMI_MAX_INTERSECTION_NUMBER && p_tri < PTMI_MAX_INTERSECTION_NUMBER, C_CHK_STATS_RANGE);  // cl:1325,1330
-        if (sc.histograms && stage_stats == nullptr) {
+        const bool given_up = !owns_pixel && (slot & kGivenUp) != 0u;  // (RANDOM sampler: redo_random_kernel adds this path)
+        if (sc.histograms && stage_stats == nullptr && !given_up) {
             // RANDOM sampler / very deep paths: the three statistics atomics as the reference issues them (:1319-1331)
             const DScene& cs = cold_scene();
             atomicAdd(&cs.hist_depths[reflection], 1u);
@@ -339,7 +349,7 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
             // Cornell box: atomics of different XCDs on one address are resolved memory-side.)
             if (stage_stats != nullptr) stage_stats[slot] = pack_path_statistics(reflection, p_bbx, p_tri);
             if (SS) cold_scene().stage_flag[slot] = 1.f;
-        } else {
+        } else if (!given_up) {
             // RANDOM sampler: the sample lands on an arbitrary pixel; the reference races there (:1339-1345).  The sample
             // position is drawn again from the path's seed (the first two draws, :1137-1141) instead of being kept.
             const uint32_t n_pixels = sc.width * sc.height;
@@ -934,10 +944,20 @@ __global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_
                 // scene_needs_literal_kernel) a distance is always a number.  So such a path is GIVEN UP here: it restarts
                 // its counters, takes a marked NaN for its radiance and its query ends before it starts - as a miss, so the
                 // next pass finishes the path the ordinary way (one segment, no hit) - and redo_poisoned_kernel, behind the
-                // launch, traces it again with the reference's literal loops.  (Not with the RANDOM sampler: nothing staged.)
+                // launch, traces it again with the reference's literal loops.  (RANDOM sampler: nothing is staged; the path
+                // goes to the launch's give-up list instead and redo_random_kernel adds it, see kGivenUp.)
                 const float o_size = __builtin_fabsf(r.o.x) + __builtin_fabsf(r.o.y) + __builtin_fabsf(r.o.z) + __builtin_fabsf(r.o.w);
                 const float d_size = __builtin_fabsf(r.d.x) + __builtin_fabsf(r.d.y) + __builtin_fabsf(r.d.z) + __builtin_fabsf(r.d.w);
-                const bool bad = owns_pixel && !((o_size <= 0x1p+40f) & (d_size <= 4.0f));  // (false for a NaN)
+                bool bad = !((o_size <= 0x1p+40f) & (d_size <= 4.0f));  // (false for a NaN)
+                if (!PLAIN && !owns_pixel && __builtin_expect(bad, 0)) {
+                    // RANDOM sampler: a place in the launch's give-up list, or (list full) carry on as before round 4
+                    const uint32_t place = atomicAdd(&job_counter[2], 1u);
+                    bad = place < kGiveUpListCap;
+                    if (bad) {
+                        job_counter[kGiveUpListFirst + place] = slot;
+                        slot |= kGivenUp;
+                    }
+                }
                 if (__builtin_expect(bad, 0)) {
                     const float m = __uint_as_float(kPoisonMarker);
                     radiance = v4(m, m, m, m);
@@ -1044,6 +1064,62 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
         }
     }
     if (lane < queued) trace_slot(queue[lane]);
+    __syncthreads();
+    if (tid > C_PATHS && tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
+    if (tid == C_PATHS && block_counters[tid] != 0ull) atomicAdd(&sc.counters[C_RETRACED], block_counters[tid]);
+}
+
+// The RANDOM sampler's form of the above: the paths a launch gave up are LISTED in its job-counter block (kGivenUp); traced
+// again by the literal loops, each adds its sample where finish_path would have - atomically, on the pixel its sample position
+// falls on (FullKernel.cl:1333-1349) - its three histogram bins and its counts.
+template <bool PRE>
+__global__ void __launch_bounds__(kBlock) redo_random_kernel(const DScene sc, const uint32_t first_iteration, const uint32_t n_iterations,
+                                                             const uint32_t iteration_stride, const uint32_t* __restrict__ job_counter)
+{
+    if (__builtin_nontemporal_load(&job_counter[1]) == 0u) return;
+    __shared__ uint32_t stack_mem[kStackDepth * kBlock];
+    __shared__ unsigned long long block_counters[C_TRI + 1];
+    const uint32_t tid = threadIdx.x;
+    if (tid <= C_TRI) block_counters[tid] = 0;
+    __syncthreads();
+    const uint32_t listed = job_counter[2], n = listed < kGiveUpListCap ? listed : kGiveUpListCap;
+    const uint32_t n_pixels = sc.width * sc.height;
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
+        const uint32_t slot = job_counter[kGiveUpListFirst + i];
+        const uint32_t it_local = slot / n_pixels, pixel = slot - it_local * n_pixels;
+        const uint32_t gy = pixel / sc.width, gx = pixel - gy * sc.width;
+        const uint32_t it = first_iteration + it_local * iteration_stride;
+        float sx, sy;
+        uint32_t depth = 0, n_seg = 0, n_shadow = 0;
+        PathCounters pc;
+        const bool ss = sc.super_sampling != 0;
+        const V4 radiance = trace_path<PRE>(sc, gx, gy, it, &stack_mem[tid], sx, sy, depth, n_seg, n_shadow, pc, ss && it > 5u);
+        if (sc.hist_depths) {  // FullKernel.cl:1319-1331
+            atomicAdd(&sc.hist_depths[depth], 1u);
+            if (pc.bbx < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_bbx[pc.bbx], 1u);
+            if (pc.tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[pc.tri], 1u);
+        }
+        const uint32_t off = sample_pixel(sc, sx, sy);
+        const V4 before = v4(atomicAdd(&sc.image_color[4 * off + 0], radiance.x), atomicAdd(&sc.image_color[4 * off + 1], radiance.y),
+                             atomicAdd(&sc.image_color[4 * off + 2], radiance.z), atomicAdd(&sc.image_color[4 * off + 3], radiance.w));
+        const float n_before = atomicAdd(&sc.image_ray_nb[off], 1.f);
+        if (ss && it != 0u) {  // cl:1346-1349, as finish_path's RANDOM branch
+            float* const vp = &sc.image_v[4 * off];
+            const V4 after = before + radiance;
+            const float n_after = n_before + 1.f;
+            atomicAdd(&vp[0], (radiance.x - fdiv(before.x, n_before)) * (radiance.x - fdiv(after.x, n_after)));
+            atomicAdd(&vp[1], (radiance.y - fdiv(before.y, n_before)) * (radiance.y - fdiv(after.y, n_after)));
+            atomicAdd(&vp[2], (radiance.z - fdiv(before.z, n_before)) * (radiance.z - fdiv(after.z, n_after)));
+            atomicAdd(&vp[3], (radiance.w - fdiv(before.w, n_before)) * (radiance.w - fdiv(after.w, n_after)));
+        }
+        // (the launch counted: one path, one segment, no hit)
+        atomicAdd(&block_counters[C_PATHS], 1ull);
+        atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)n_seg - 1ull);
+        atomicAdd(&block_counters[C_HITS], (unsigned long long)depth);
+        atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
+        atomicAdd(&block_counters[C_BBX], (unsigned long long)pc.bbx);
+        atomicAdd(&block_counters[C_TRI], (unsigned long long)pc.tri);
+    }
     __syncthreads();
     if (tid > C_PATHS && tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
     if (tid == C_PATHS && block_counters[tid] != 0ull) atomicAdd(&sc.counters[C_RETRACED], block_counters[tid]);
@@ -1200,12 +1276,19 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
     if (n_iterations == 0) return PTMI_OK;
     const uint32_t tiles = ((sc.width + 7u) / 8u) * ((sc.height + 7u) / 8u);
     const uint64_t jobs64 = (uint64_t)tiles * 64u * n_iterations;
-    if (jobs64 > 0xFFFFFFF0ull) {
+    if (jobs64 > (sc.sampler == PTMI_SAMPLER_RANDOM ? 0x7FFFFFF0ull : 0xFFFFFFF0ull)) {  // (RANDOM: bit 31 of a slot word is kGivenUp)
         if (err) *err = "too many jobs in one launch";
         return PTMI_ERR_INVALID_ARGUMENT;
     }
     const uint32_t n_jobs = (uint32_t)jobs64;
     hipError_t e = hipMemsetAsync(job_counter, 0, PTMI_DEV_NS::kQueues * PTMI_DEV_NS::kQueueStride * sizeof(uint32_t), (hipStream_t)stream);
+    if (e == hipSuccess && sc.sampler == PTMI_SAMPLER_RANDOM) {
+        // PTMI_RANDOM_GIVE_UP=0 (tests, A/B): the give-up list starts full, so a path whose ray is not a number carries on with
+        // the ordered minimum as before round 4
+        const char* off = std::getenv("PTMI_RANDOM_GIVE_UP");
+        if (off && off[0] == '0')
+            e = hipMemsetD32Async((hipDeviceptr_t)(job_counter + 2), (int)PTMI_DEV_NS::kGiveUpListCap, 1, (hipStream_t)stream);
+    }
     if (e == hipSuccess) {
         uint32_t blocks = (n_jobs + PTMI_DEV_NS::kWfBlock - 1) / PTMI_DEV_NS::kWfBlock;
         const dim3 b(PTMI_DEV_NS::kWfBlock);
@@ -1266,6 +1349,16 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
 #undef PTMI_LAUNCH_WF
 #undef PTMI_LAUNCH_WF_IMPL
         e = hipGetLastError();
+        if (e == hipSuccess && stage == nullptr && sc.sampler == PTMI_SAMPLER_RANDOM) {
+            // RANDOM sampler: behind the launch, the paths on its give-up list (returns at once when there is none)
+            if (sc.tris_precomputed)
+                hipLaunchKernelGGL(PTMI_DEV_NS::redo_random_kernel<true>, dim3(64), dim3(PTMI_DEV_NS::kBlock), 0, st, sc, first_iteration,
+                                   n_iterations, iteration_stride, job_counter);
+            else
+                hipLaunchKernelGGL(PTMI_DEV_NS::redo_random_kernel<false>, dim3(64), dim3(PTMI_DEV_NS::kBlock), 0, st, sc, first_iteration,
+                                   n_iterations, iteration_stride, job_counter);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess && stage != nullptr) {
             // behind the launch, on its stream: the paths it gave up, if any (returns at once otherwise)
             if (sc.tris_precomputed)

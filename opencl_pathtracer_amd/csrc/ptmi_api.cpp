@@ -944,7 +944,7 @@ int ptmi_setup_context(ptmi_ctx** out, const ptmi_config* cfg)
     // iterations per launch: at most 16, fewer for very large images (32-bit job ids, staging array <= 4 GiB)
     {
         const uint64_t tiles = (uint64_t)((cfg->image_width + 7u) / 8u) * ((cfg->image_height + 7u) / 8u);
-        const uint64_t by_jobs = 0xFFFFFFF0ull / (tiles * 64u);
+        const uint64_t by_jobs = (cfg->sampler == PTMI_SAMPLER_RANDOM ? 0x7FFFFFF0ull : 0xFFFFFFF0ull) / (tiles * 64u);  // (kernel_wavefront.hip: kGivenUp)
         const uint64_t by_bytes = (4ull << 30) / ((uint64_t)cfg->image_width * cfg->image_height * 20u);
         uint64_t cap = kMaxIterationsPerLaunch;
         if (by_jobs < cap) cap = by_jobs;

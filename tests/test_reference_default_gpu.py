@@ -194,6 +194,45 @@ def test_random_sampler_vs_reference_default_build(scene_factory):
     assert close[same].mean() > 0.75 and close.mean() > 0.6  # (measured: 0.85 and 0.76; the race decides)
 
 
+def test_random_sampler_paths_with_nan_rays_are_traced_again(monkeypatch):
+    """fuzz47r: a few paths in a million scatter into a direction that is not a number (a refraction's square root of a negative,
+    cl:235,249); the reference then accepts triangles with NaN distances and keeps the LAST that passes.  With the RANDOM sampler
+    nothing is staged, so the wavefront kernel LISTS such a path in the launch's job-counter block and redo_random_kernel traces it
+    again with the literal loops and adds it atomically (round 4; before, the path kept the ordered minimum).  The paths of a
+    RANDOM-sampler render are a function of (work-item, iteration) like any other, and the reference's histograms are atomics:
+    all three equal the reference kernel's, built -D SAMPLE_RANDOM with its own options - and so do the one-path-per-lane
+    kernel's and the oracle's totals."""
+    import warnings
+    case, w, h, d, spp = "fuzz_96x64_d10_rnd", 96, 64, 10, 2048
+    if not O.have_ref_kernel(case):
+        O.missing_reference("oracle/_ref code object not present")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc = bvh_create(scenes.build("fuzz47r_l1", w, h))
+    be = backend.Backend().setup_context(w, h, d, 1, S.RANDOM, flags=DA)
+    try:
+        be.initialize_memory(sc)
+        assert be.literal_kernel_reason() is None
+        be.render(0, spp)
+        color, count = be.read_image()
+        dep, bbx, tri = be.read_statistics()
+        counters = be.counters()
+        retraced = be.scheduler_stats()["paths_retraced"]
+    finally:
+        be.release()
+    assert 0 < retraced < 1000, retraced  # (measured: 37 of 12.6 M)
+    r_color, r_count, (r_dep, r_bbx, r_tri), _ = O.ref_gpu_render(case, sc, w, h, d, spp)
+    assert np.array_equal(dep, r_dep) and np.array_equal(bbx, r_bbx) and np.array_equal(tri, r_tri)
+    assert (r_count <= count).all() and count.sum() == w * h * spp
+    # the one-path-per-lane kernel (the reference's loops as they are written): the same histograms, counts and totals
+    lit = render_scene(sc, w, h, d, spp, sampler=S.RANDOM, flags=DA | backend.FLAG_MEGAKERNEL)
+    assert all(np.array_equal(a, b) for a, b in zip((dep, bbx, tri), lit[2])) and np.array_equal(count, lit[1]) and counters == lit[3]
+    # ... and with the re-trace switched off by an empty list (a launch of the old kind), the histograms differ: the test tests
+    monkeypatch.setenv("PTMI_RANDOM_GIVE_UP", "0")
+    old = render_scene(sc, w, h, d, spp, sampler=S.RANDOM, flags=DA)
+    assert not (np.array_equal(old[2][1], r_bbx) and np.array_equal(old[2][2], r_tri))
+
+
 FUZZ_SPECIALISATIONS = ((1, "feat_64x64_d8", 64, 64, 8), (3, "matmix_96x96_d8", 96, 96, 8))  # lights, reference code object, W, H, depth
 
 

@@ -38,4 +38,4 @@ def test_wavefront_kernel_keeps_five_waves_per_simd(arithmetic):
         assert figures["loop scratch"] <= (2 if nan_safe else 0), (key, figures)
     # the instrumented ones (<true, ...>: --scheduler-stats, SUPER_SAMPLING) carry more state and may reload a few words
     for key, figures in res.items():
-        assert figures["VGPRs"] <= 96 and figures["Occupancy"] >= 5 and figures["loop scratch"] <= 8, (key, figures)
+        assert figures["VGPRs"] <= 96 and figures["Occupancy"] >= 5 and figures["loop scratch"] <= 12, (key, figures)
