@@ -264,7 +264,7 @@ def main():
                          "frac": rate / L1_ACCESS_RATE, "ceiling": L1_CEILING_SOURCE,
                          "pmc_fallback": "LOUD: no PMC passes of this kernel source are committed for this workload - the counter-backed "
                                          "table (binding, traffic, hbm_measured) is missing from this line; run tools/profile_round.sh",
-                         "note": "no committed PMC passes match this kernel source + workload + arithmetic (profiles/r03_pmc_*.json): the L1 "
+                         "note": "no committed PMC passes match this kernel source + workload + arithmetic (profiles/r04_pmc_*.json): the L1 "
                                  f"access rate is ESTIMATED as records fetched x {L1_ACCESSES_PER_RECORD} accesses per record (measured for this "
                                  "kernel on the 1M-triangle workload) against the gather ceiling of tools/microbench/record_fetch; run "
                                  "tools/profile_round.sh for the measured table"})
@@ -355,10 +355,12 @@ def kernel_source_digest():
 
 def committed_pmc(args, W, H, D, B):
     """Per-launch means of the rocprofv3 --pmc passes of THIS command line (tools/profile_round.sh: one counter group per
-    run, summarised by tools/summarize_pmc.py), committed as profiles/r03_pmc_<scene>_<arithmetic>.json.  bench.py itself
+    run, summarised by tools/summarize_pmc.py), committed as profiles/r04_pmc_<scene>_<arithmetic>.json.  bench.py itself
     cannot read PMC counters; the file is used only for the configuration AND the kernel source it was measured on."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.scene}_{args.arithmetic}.json")
-    if not os.path.exists(path) or args.kernel != "wavefront":
+    # (the newest round's passes first; older ones are only quoted if they were taken on this very kernel source, below)
+    path = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_pmc_{args.scene}_{args.arithmetic}.json") for r in ("r04", "r03"))
+                 if os.path.exists(p)), None)
+    if path is None or args.kernel != "wavefront":
         return None
     pmc = json.load(open(path))
     if pmc.get("_config") != {"scene": args.scene, "width": W, "height": H, "depth": D, "arithmetic": args.arithmetic}:
@@ -372,7 +374,7 @@ def committed_pmc(args, W, H, D, B):
     if pmc.get("_kernel_source_digest") != kernel_source_digest():
         return None
     pmc["_path"] = os.path.relpath(path, ROOT)
-    mpath = os.path.join(ROOT, "profiles", f"r03_valu_cost_model_{args.scene}_{args.arithmetic}.json")
+    mpath = os.path.join(ROOT, "profiles", os.path.basename(path).replace("_pmc_", "_valu_cost_model_"))
     if os.path.exists(mpath):
         model = json.load(open(mpath))
         if model.get("sources", {}).get("kernel_source_digest") == pmc["_kernel_source_digest"]:

@@ -214,8 +214,14 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
 // ray is not a number, and redo_poisoned_kernel traces it again with the literal loops.  Everything else - and every path that
 // never reaches such a record - is the ordinary kernel.  (A shadow query needs nothing: it ends at the FIRST accepted triangle
 // in index order whatever the distances are, and its limit never changes.)  Clean scenes run the instantiations without it.
-template <bool STATS, bool PRE, bool SS, bool PLAIN = false, bool NANSAFE = false>
-__global__ void __launch_bounds__(kWfBlock, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN_WAVES_GENERAL) render_wavefront_kernel(
+// WAVES (0 = the default of the kind): the waves per SIMD the register allocator must fit.  Trees of 23 levels and more need
+// 32 KB of LDS per workgroup and more, so a CU holds FOUR workgroups of them whatever the registers allow; the general shading
+// instantiation is then also built for four waves (128 registers, no spilled register instead of 30) and that build is launched
+// where the occupancy query says the five-wave one gets four anyway: configs[4] stand-in (depth 23) 1209 -> 1239 Msamples/s, same
+// box.  (At five workgroups per CU the four-wave build loses 9 %: 974 -> 889 on the 1M-triangle scene.  The plain kernel gains
+// nothing from it on the 4M-triangle scene, depth 24: 516.6 / 517.0.)
+template <bool STATS, bool PRE, bool SS, bool PLAIN = false, bool NANSAFE = false, int WAVES = 0>
+__global__ void __launch_bounds__(kWfBlock, WAVES ? WAVES : (PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN_WAVES_GENERAL)) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc_arg, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t iteration_stride,
                                                                     const uint32_t n_jobs,
@@ -1343,7 +1349,27 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
             else PTMI_LAUNCH_WF(false, false, false, true);
         } else {
             if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true, false);  // the common case, BASELINE's untextured scenes among them
-            else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, false);
+            else if (sc.tris_precomputed) {
+                // deep trees: LDS holds four workgroups per CU -> the 128-register build (see WAVES); asked once per device and depth
+                static std::atomic<int> grid_of_four[kMaxCachedDevices][PTMI_BVH_MAX_DEPTH + 1];  // 0 = not asked, -1 = five fit, else its grid
+                int grid4 = cached_device ? grid_of_four[device][lv].load(std::memory_order_relaxed) : 0;
+                if (grid4 == 0) {
+                    int n_cu = 0;
+                    const int five = resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, false, false>, lv);
+                    const bool four = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0 &&
+                                      five > 0 && five < 5 * n_cu;
+                    grid4 = four ? resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, false, false, 4>, lv) : -1;
+                    if (grid4 == 0) grid4 = -1;
+                    if (cached_device) grid_of_four[device][lv].store(grid4, std::memory_order_relaxed);
+                }
+                if (grid4 > 0) {
+                    uint32_t nb = blocks;
+                    if (nb > (uint32_t)grid4) nb = (uint32_t)grid4;
+                    hipLaunchKernelGGL((PTMI_DEV_NS::render_wavefront_kernel<false, true, false, false, false, 4>), dim3(nb), b, lds, st,
+                                       scene_in_device_memory, warm, first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage,
+                                       stage_stats);
+                } else PTMI_LAUNCH_WF(false, true, false, false);
+            }
             else PTMI_LAUNCH_WF(false, false, false, false);
         }
 #undef PTMI_LAUNCH_WF

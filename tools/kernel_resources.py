@@ -23,16 +23,16 @@ def resources(tree=ROOT, arithmetic=1, extra=()):
         raise RuntimeError(r.stderr[-3000:])
     res = {}
     for block in re.split(r"Function Name: ", r.stderr)[1:]:
-        m = re.match(r"\w+?23render_wavefront_kernelI((?:Lb[01]E)+)E", block)
+        m = re.match(r"\w+?23render_wavefront_kernelI((?:Lb[01]E)+)(?:Li(\d+)E)?E", block)
         if not m:
             continue
-        key = "".join(re.findall(r"Lb([01])E", m.group(1)))  # STATS PRE SS PLAIN NANSAFE
+        key = "".join(re.findall(r"Lb([01])E", m.group(1))) + ("w" + m.group(2) if m.group(2) not in (None, "0") else "")  # STATS PRE SS PLAIN NANSAFE [wN]
         res[key] = {k.strip(): int(v) for k, v in re.findall(r"remark: [^\n]*?\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", block)}
     name, depth2 = None, False
     for line in open(out):
-        m = re.match(r"\w+?23render_wavefront_kernelI((?:Lb[01]E)+)E\w*:", line)
+        m = re.match(r"\w+?23render_wavefront_kernelI((?:Lb[01]E)+)(?:Li(\d+)E)?E\w*:", line)
         if m:
-            name, depth2 = "".join(re.findall(r"Lb([01])E", m.group(1))), False
+            name, depth2 = "".join(re.findall(r"Lb([01])E", m.group(1))) + ("w" + m.group(2) if m.group(2) not in (None, "0") else ""), False
             res[name]["loop"] = Counter()
         elif re.match(r"(\.LBB|; %bb\.)", line):
             depth2 = "Depth=2" in line
@@ -53,5 +53,5 @@ if __name__ == "__main__":
     print("STATS PRE SS PLAIN NANSAFE | VGPRs spilled scratch occupancy | traversal loop: scratch VALU SALU LDS VMEM")
     for k in sorted(res):
         v = res[k]
-        print("   ".join(k), "|", v["VGPRs"], v["VGPRs Spill"], v["ScratchSize"], v["Occupancy"], "|", v["loop scratch"], v["loop VALU"], v["loop SALU"],
+        print("   ".join(k[:5]) + ("  " + k[5:] if len(k) > 5 else ""), "|", v["VGPRs"], v["VGPRs Spill"], v["ScratchSize"], v["Occupancy"], "|", v["loop scratch"], v["loop VALU"], v["loop SALU"],
               v["loop LDS"], v["loop VMEM"])

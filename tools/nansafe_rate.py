@@ -16,7 +16,7 @@ import opencl_pathtracer_amd as pt  # noqa: E402
 from opencl_pathtracer_amd import backend, scenes  # noqa: E402
 from opencl_pathtracer_amd import structs as S  # noqa: E402
 
-W, H, D, SPP, REPS = 1920, 1080, 10, 16, 3
+W, H, D, SPP, REPS = 1920, 1080, 10, 8, 9
 DA = backend.FLAG_DEFAULT_ARITHMETIC
 
 
@@ -32,9 +32,12 @@ def rate(sc, flags, env=None, spp=None, reps=None):
         be.synchronize()
         c0 = be.counters()
         t0 = time.perf_counter()
+        per_launch = []
         for r in range(reps):
+            t1 = time.perf_counter()
             be.render(r * spp, spp)
             be.synchronize()
+            per_launch.append(time.perf_counter() - t1)
             print(f"    {r + 1}/{reps} after {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
         dt = time.perf_counter() - t0
         c1 = be.counters()
@@ -45,7 +48,10 @@ def rate(sc, flags, env=None, spp=None, reps=None):
         for k in (env or {}):
             del os.environ[k]
     seg = c1["segments"] - c0["segments"]
+    med = sorted(per_launch)[len(per_launch) // 2]
     return {"Msamples/s": seg / dt / 1e6, "Mpaths/s": (c1["paths"] - c0["paths"]) / dt / 1e6, "paths_retraced": st["paths_retraced"],
+            # launches differ where a rare path walks the whole tree ten times over (a NaN record as its FINAL hit): seconds, anywhere
+            "seconds_per_launch": [round(x, 4) for x in per_launch], "Msamples/s_at_the_median_launch": seg / reps / med / 1e6,
             "paths": c1["paths"], "iterations_per_launch": spp, "launches": reps,
             "literal_kernel_reason": why.decode() if isinstance(why, bytes) else why}
 
@@ -118,6 +124,8 @@ def entry(name, clean, hostile, removed=None):
         e["reference_kernel_on_the_hostile_scene"] = ref
         e["nansafe_over_reference_kernel"] = e["hostile_wavefront_nansafe"]["Mpaths/s"] / ref["Mpaths/s"]
     e["nansafe_over_clean"] = e["hostile_wavefront_nansafe"]["Msamples/s"] / e["clean_wavefront"]["Msamples/s"]
+    e["nansafe_over_clean_at_the_median_launch"] = (e["hostile_wavefront_nansafe"]["Msamples/s_at_the_median_launch"] /
+                                                    e["clean_wavefront"]["Msamples/s_at_the_median_launch"])
     e["nansafe_over_one_path_per_lane"] = e["hostile_wavefront_nansafe"]["Msamples/s"] / e["hostile_one_path_per_lane"]["Msamples/s"]
     e["share_of_paths_retraced"] = e["hostile_wavefront_nansafe"]["paths_retraced"] / e["hostile_wavefront_nansafe"]["paths"]
     out["scenes"][name] = e

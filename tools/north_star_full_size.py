@@ -4,7 +4,7 @@ produces (oracle/_ref/ref_kernel_*.hsaco, OpenCL default arithmetic), run beside
     configs[1]  Cornell box,          1920x1080, depth 8, 1024 spp   (~56 s)
 Per config: per-channel RMS of the default-arithmetic mode (expected 0: the images are equal bit for bit) and of the strict
 mode (= the reference's own strict-vs-default distance, tests/test_parity_gpu.py) vs that kernel, equality of counts and
-histograms, and both kernels' path rates.  Writes gpurun_out/r03_north_star_full_size.json (copied to profiles/).
+histograms, and both kernels' path rates.  Writes gpurun_out/r04_north_star_full_size.json (copied to profiles/).
 usage: python tools/north_star_full_size.py [tris1m|cornell ...] [--spp-scale F]"""
 import json
 import os
@@ -39,7 +39,7 @@ def ours(sc, w, h, d, spp, flags):
 def main():
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(CONFIGS)
     scale = float(sys.argv[sys.argv.index("--spp-scale") + 1]) if "--spp-scale" in sys.argv else 1.0
-    out_path = os.path.join(ROOT, "gpurun_out", "r03_north_star_full_size.json")
+    out_path = os.path.join(ROOT, "gpurun_out", "r04_north_star_full_size.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
     for nm in names:
         case, scene, w, h, d, spp, what = CONFIGS[nm]

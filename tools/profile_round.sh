@@ -2,7 +2,7 @@
 # Collect the rocprofv3 evidence bench.py's roofline refers to (run from the repo root ON THE GPU BOX):
 #   1. kernel trace + stats of the bench command              -> gpurun_out/prof_$TAG/wf_kernel_stats.csv
 #   2. one --pmc pass per counter group (never mixed with other trace domains) -> gpurun_out/pmc_$TAG/*.csv
-#   3. tools/summarize_pmc.py                                -> gpurun_out/pmc_$TAG.json (copy to profiles/r03_pmc_<scene>_<arithmetic>.json)
+#   3. tools/summarize_pmc.py                                -> gpurun_out/pmc_$TAG.json (copy to profiles/r04_pmc_<scene>_<arithmetic>.json)
 # usage: tools/profile_round.sh TAG [bench.py flags, e.g. --scene tris4m]
 set -e
 TAG=${1:?tag}; shift

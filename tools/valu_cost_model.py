@@ -4,7 +4,7 @@
 No counter of gfx950 separates the VALU instructions by what they cost their SIMD (SQ_ACTIVE_INST_VALU counts in quad-cycles,
 one per instruction: it cannot tell a 2-cycle v_fma_f32 from a 4-cycle v_pk_fma_f32).  So the cost is priced from the code:
 
-  1. the ISA of the production kernel (render_wavefront_kernel<false, true, false, true>, the arithmetic given) is split into
+  1. the ISA of the production kernel (render_wavefront_kernel<false, true, false, true, false, 0>, the arithmetic given) is split into
      its three kinds of wave-level work - NODE TRIP, LEAF PASS (both in the depth-2 traversal loop) and PATH-LOGIC PASS (the
      depth-1 remainder of the main loop) - and every vector instruction of each is put in a cost class with the cycle costs
      tools/microbench/pk_rate.hip measured on the MI355X: 8 for transcendentals (v_rcp / v_rsq / v_sqrt / v_sin / v_cos / v_exp /
@@ -20,7 +20,7 @@ Blocks that only run for rare rays (the literal 13-comparison box test of a wave
 component) are left out of a trip's static count; everything else counts once per trip - an over-estimate for the blocks a
 trip skips when no lane needs them, which the check in 3. bounds.
 
-usage: tools/valu_cost_model.py BENCH_JSON_WITH_SCHEDULER_STATS PMC_JSON [--arithmetic default|strict] [--general] > profiles/r03_valu_cost_model_<scene>.json
+usage: tools/valu_cost_model.py BENCH_JSON_WITH_SCHEDULER_STATS PMC_JSON [--arithmetic default|strict] [--general] > profiles/r04_valu_cost_model_<scene>.json
 (--general: the general shading instantiation - textures, all material and light types - instead of the plain-scene one)
 """
 import json
@@ -52,7 +52,8 @@ def kernel_blocks(arith, general=False):
                           "-Iinclude", "-Iopencl_pathtracer_amd/csrc", f"-DPTMI_DEFAULT_ARITHMETIC={1 if arith == 'default' else 0}",
                           "--cuda-device-only", "-S", "opencl_pathtracer_amd/csrc/kernel_wavefront.hip", "-o", "-"],
                          cwd=ROOT, check=True, capture_output=True, text=True).stdout.split("\n")
-    tag = "ILb0ELb1ELb0ELb0E" if general else "ILb0ELb1ELb0ELb1E"  # general / plain-scene shading (what the workload's launches pick)
+    # general / plain-scene shading (what the workload's launches pick); <STATS, PRE, SS, PLAIN, NANSAFE>
+    tag = "ILb0ELb1ELb0ELb0ELb0ELi0EE" if general else "ILb0ELb1ELb0ELb1ELb0ELi0EE"
     start = next(i for i, l in enumerate(asm) if l.startswith(f"_ZN{ns}23render_wavefront_kernel{tag}"))
     end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
     blocks, cur = [], None
