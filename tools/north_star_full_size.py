@@ -2,6 +2,7 @@
 produces (oracle/_ref/ref_kernel_*.hsaco, OpenCL default arithmetic), run beside the integrator on this GPU:
     configs[2]  ~1M random triangles, 1920x1080, depth 10, 256 spp   (the reference kernel needs ~36 s)
     configs[1]  Cornell box,          1920x1080, depth 8, 1024 spp   (~56 s)
+    configs[4]  stand-in (scenes.maya_like), 3840x2160, depth 16, 64 of its 2048 spp   (~17 s)
 Per config: per-channel RMS of the default-arithmetic mode (expected 0: the images are equal bit for bit) and of the strict
 mode (= the reference's own strict-vs-default distance, tests/test_parity_gpu.py) vs that kernel, equality of counts and
 histograms, and both kernels' path rates.  Writes gpurun_out/r04_north_star_full_size.json (copied to profiles/).
@@ -20,7 +21,9 @@ import oracle_ffi as O  # noqa: E402
 from opencl_pathtracer_amd import Backend, scenes, bvh_create, backend  # noqa: E402
 
 CONFIGS = {"tris1m": ("tris1m_1920x1080_d10", "tris1m", 1920, 1080, 10, 256, "BASELINE configs[2]"),
-           "cornell": ("cornell_1920x1080_d8", "cornell", 1920, 1080, 8, 1024, "BASELINE configs[1]")}
+           "cornell": ("cornell_1920x1080_d8", "cornell", 1920, 1080, 8, 1024, "BASELINE configs[1]"),
+           # configs[4]'s stand-in (SURVEY 8d Config 5) at its full size; 64 of its 2048 spp (the reference kernel needs 17 s for them)
+           "mayalike": ("mayalike_3840x2160_d16", "mayalike", 3840, 2160, 16, 64, "BASELINE configs[4] stand-in, 64 of 2048 spp")}
 
 
 def ours(sc, w, h, d, spp, flags):
