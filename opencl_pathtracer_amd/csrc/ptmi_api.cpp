@@ -80,6 +80,7 @@ struct DeviceState {
     // it left off (ids first + n, same n), so a caller that jumps around pays nothing
     bool have_last = false;
     uint32_t last_first = 0, last_n = 0, last_stride = 0;
+    hipEvent_t previous_call_done = nullptr;  // the event behind the previous call's work on the main stream
     uint32_t launches_issued = 0;
     DScene ds{};
     DScene* d_scene = nullptr;  // device copy of ds (what the wavefront kernel's path logic reads)
@@ -182,6 +183,7 @@ void free_scene_memory(ptmi_ctx* ctx)
             if (d.launch_stream[i]) (void)hipStreamSynchronize(d.launch_stream[i]);
         d.ahead.clear();
         d.have_last = false;
+        d.previous_call_done = nullptr;
         (void)hipStreamSynchronize(d.stream);
         if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
         for (void* p : d.allocations) (void)hipFree(p);
@@ -618,7 +620,12 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
             // keep the next launches of a caller that comes back for one short call after the other in flight
             const bool continues = d.have_last && d.last_n == n && d.last_stride == stride &&
                                    (uint64_t)d.last_first + (uint64_t)n * stride == (uint64_t)first;
-            if (can_run_ahead && continues && rc == PTMI_OK && e == hipSuccess) {
+            // ... and only ahead of a caller that WAITS: if what the previous call asked for was still running when this call
+            // came, the caller keeps the GPU busy by itself (launches queued ahead of its readbacks) and more launches in
+            // flight would only be in its way
+            const bool caller_waits = d.previous_call_done == nullptr || hipEventQuery(d.previous_call_done) == hipSuccess;
+            (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+            if (can_run_ahead && continues && caller_waits && rc == PTMI_OK && e == hipSuccess) {
                 uint64_t next = d.ahead.empty() ? (uint64_t)first + (uint64_t)n * stride : (uint64_t)d.ahead.back().first + (uint64_t)n * stride;
                 while ((int)d.ahead.size() < render_ahead_depth() && next + (uint64_t)(n - 1) * stride <= 0xFFFFFFFFull &&
                        rc == PTMI_OK && e == hipSuccess) {
@@ -638,6 +645,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
         return fail(ctx, PTMI_ERR_HIP, std::string("launch sequencing: ") + hipGetErrorString(e));
     }
     d.pending_events.push_back(ev);
+    d.previous_call_done = ev.second;  // (stays valid in the pool: fold_events only moves the pair to free_events)
     d.have_last = true;
     d.last_first = first; d.last_n = n; d.last_stride = stride;
     return PTMI_OK;

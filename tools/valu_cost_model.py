@@ -21,7 +21,8 @@ component) are left out of a trip's static count; everything else counts once pe
 trip skips when no lane needs them, which the check in 3. bounds.
 
 usage: tools/valu_cost_model.py BENCH_JSON_WITH_SCHEDULER_STATS PMC_JSON [--arithmetic default|strict] [--general] > profiles/r04_valu_cost_model_<scene>.json
-(--general: the general shading instantiation - textures, all material and light types - instead of the plain-scene one)
+(--general: the general shading instantiation - textures, all material and light types - instead of the plain-scene one;
+ --four-waves: its 128-register build, which deep trees run)
 """
 import json
 import os
@@ -46,14 +47,14 @@ def cost_class(op):
     return 2
 
 
-def kernel_blocks(arith, general=False):
+def kernel_blocks(arith, general=False, waves=0):
     ns = "11ptmi_dev_da" if arith == "default" else "8ptmi_dev"
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                           "-Iinclude", "-Iopencl_pathtracer_amd/csrc", f"-DPTMI_DEFAULT_ARITHMETIC={1 if arith == 'default' else 0}",
                           "--cuda-device-only", "-S", "opencl_pathtracer_amd/csrc/kernel_wavefront.hip", "-o", "-"],
                          cwd=ROOT, check=True, capture_output=True, text=True).stdout.split("\n")
     # general / plain-scene shading (what the workload's launches pick); <STATS, PRE, SS, PLAIN, NANSAFE>
-    tag = "ILb0ELb1ELb0ELb0ELb0ELi0EE" if general else "ILb0ELb1ELb0ELb1ELb0ELi0EE"
+    tag = f"ILb0ELb1ELb0ELb0ELb0ELi{waves}EE" if general else "ILb0ELb1ELb0ELb1ELb0ELi0EE"
     start = next(i for i, l in enumerate(asm) if l.startswith(f"_ZN{ns}23render_wavefront_kernel{tag}"))
     end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
     blocks, cur = [], None
@@ -85,7 +86,8 @@ def main():
     pmc = json.load(open(sys.argv[2]))
     arith = sys.argv[sys.argv.index("--arithmetic") + 1] if "--arithmetic" in sys.argv else bench.get("arithmetic", "default")
     general = "--general" in sys.argv
-    blocks = kernel_blocks(arith, general)
+    waves = 4 if "--four-waves" in sys.argv else 0  # (the 128-register build of the general kernel: trees of 23 levels and more)
+    blocks = kernel_blocks(arith, general, waves)
     loop2 = [b for b in blocks if b["depth"] == 2]
     # the traversal loop holds the node trip first, then the leaf pass: the pass starts at the block that builds the item
     # numbering (the only v_mbcnt of the loop) - the block before it is its scalar "is a pass due" test
@@ -105,7 +107,7 @@ def main():
     v = lambda k: pmc[k]["per_launch_mean"]
     cycles = v("GRBM_GUI_ACTIVE") / 8.0
     measured_n = v("SQ_INSTS_VALU")
-    out = {"kernel": f"render_wavefront_kernel<false,true,false,{'false' if general else 'true'}> ({arith} arithmetic)", "workload": bench["config"]["workload"],
+    out = {"kernel": f"render_wavefront_kernel<false,true,false,{'false' if general else 'true'},false,{waves}> ({arith} arithmetic)", "workload": bench["config"]["workload"],
            "cycle_costs": "tools/microbench/pk_rate.hip on MI355X: 2 plain 32-bit, 4 packed fp32 / 64-bit / min3-max3 / compares / lane ops, 8 transcendental",
            "static_per_trip": regions, "trips_per_launch": w,
            "predicted_valu_instructions_per_launch": pred_n, "measured_SQ_INSTS_VALU_per_launch": measured_n,
