@@ -243,7 +243,7 @@ int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out);
 /* NaN distances.  The reference's triangle test (FullKernel.cl:519-589) rejects with comparisons only, so a triangle on which
  * it computes NaNs is ACCEPTED, with a NaN distance, and from then on the LAST triangle that passes wins, not the nearest.
  * The integrator reproduces that bit for bit.  Where the RAY is not a number (a refraction at |cos| = 1 + 1 ulp, cl:235) the
- * wavefront kernel gives the path up and re-traces it with the reference's literal loops (JITTERED / UNIFORM samplers).
+ * wavefront kernel gives the path up and re-traces it with the reference's literal loops (every sampler; RANDOM: a give-up list).
  * Where the scene's RECORDS are the source - zero-area triangles, whose normal the importer computes as 0/0; non-finite or
  * astronomically large coordinates - this call returns why (else NULL), and the scene is rendered by an instantiation of the
  * wavefront kernel that looks at every accepted triangle of a closest-hit query: only the paths that REACH such a record are

@@ -357,6 +357,8 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     ds.tris_precomputed = lay.tris_precomputed ? 1u : 0u;
     ds.plain_shading = lay.plain_shading ? 1u : 0u;
     ds.nan_safe = lay.literal_kernel_reason.empty() ? 0u : 1u;
+    ds.nan_walk_box_tests = lay.nan_walk_box_tests; ds.nan_walk_tri_tests = lay.nan_walk_tri_tests; ds.nan_walk_last_tri = lay.nan_walk_last_tri;
+    if (std::getenv("PTMI_WALK_NAN_RAYS") != nullptr) ds.nan_walk_box_tests = ds.nan_walk_tri_tests = 0xFFFFFFFFu;  // developer switch: A/B and tests
     ds.boxes_ordered = (lay.boxes_ordered && std::getenv("PTMI_GENERIC_BOXES") == nullptr) ? 1u : 0u;  // env: developer switch for A/B runs
     ds.root_ref = lay.root_ref;
     ds.width = ctx->cfg.image_width;

@@ -143,6 +143,8 @@ struct DScene {
     uint32_t tris_precomputed; // tris[] holds DTriPre records
     uint32_t plain_shading;    // every material a plain-colour MAT_STANDART and every light a LIGHT_POINT
     uint32_t nan_safe;         // the records can yield NaN distances (scene_needs_literal_kernel): the wavefront kernel's NANSAFE instantiation
+    // the walk of a ray whose direction is NaN in every component (scene_layout.h: Relayout::nan_walk_*; 0xFFFFFFFF tests: walk it)
+    uint32_t nan_walk_box_tests, nan_walk_tri_tests, nan_walk_last_tri;
     uint32_t n_records;        // nodes + leaf triangles in the one record array (nodes == tris)
     uint32_t wide_records;     // that array is 4 GB or more: byte offsets need 64 bits
     uint32_t boxes_ordered;    // every non-empty child box is finite with pMin <= pMax (see box_hit_ordered)

@@ -25,6 +25,21 @@ template <bool ANY_HIT, bool PRE>
 __device__ __forceinline__ bool traverse(const DScene& sc, const Ray& r, float limit, Hit& hit, PathCounters& pc,
                                          uint32_t* __restrict__ stack)
 {
+    // A closest-hit query of a ray whose direction is NaN in every component (the scattered ray of a hit on a zero-area
+    // triangle, whose normal is 0/0): every comparison of the box test and of the triangle test is false, so every non-empty
+    // box is "hit" and every triangle accepted - the query walks the WHOLE tree in one fixed order and keeps its last triangle
+    // (seconds for one path on a million triangles, ten times per path).  The upload has walked it once
+    // (scene_layout.cpp: nan_walk_*): the counts are added and the LAST triangle's test is made for real, which leaves the
+    // very record, bit for bit, that the walk would leave.
+    if (!ANY_HIT && sc.nan_walk_box_tests != 0xFFFFFFFFu && (r.d.x != r.d.x) & (r.d.y != r.d.y) & (r.d.z != r.d.z)) {
+        pc.bbx += sc.nan_walk_box_tests;
+        pc.tri += sc.nan_walk_tri_tests;
+        if (sc.nan_walk_last_tri == 0xFFFFFFFFu) return false;
+        const float4* q4 = reinterpret_cast<const float4*>(&sc.tris[sc.nan_walk_last_tri]);
+        const bool accepted = tri_hit_record<PRE>(q4[0], q4[1], q4[2], q4[3], r, limit, hit);
+        hit.tri = sc.nan_walk_last_tri;
+        return accepted;
+    }
     bool found = false;
     int top = 0;
     uint32_t cur = sc.root_ref;

@@ -277,6 +277,43 @@ int build_layout(const ptmi_config& cfg, const ptmi_scene* sc, Relayout& out, st
     // the traversal stack has 30 entries (FullKernel.cl:627); the reference refuses deeper trees (PathTracer.cpp:54-58)
     if (out.max_depth >= PTMI_BVH_MAX_DEPTH)
         return fail(err, PTMI_ERR_LIMIT, "bvh depth " + std::to_string(out.max_depth) + " >= 30");
+    // The walk of a ray whose direction is NaN in every component (Relayout::nan_walk_*): BVH_IntersectRay (FullKernel.cl:620-702)
+    // with every box test answering "not empty" and dir[cutAxis] > 0 false - son2 first, son1 pushed (:660-697).
+    {
+        uint64_t boxes = 0, tris = 0;
+        uint32_t last = 0xFFFFFFFFu;
+        std::vector<uint32_t> stack;
+        uint32_t cur = out.root_ref;
+        for (;;) {
+            if (cur & REF_LEAF) {
+                uint32_t count = (cur >> REF_COUNT_SHIFT) & 7u, start = cur & REF_INDEX_MASK_LEAF;
+                if (count == REF_COUNT_BIG) { const DBigLeaf& bl = out.big_leaves[start]; start = bl.start; count = bl.count; }
+                tris += count;
+                if (count) last = start + count - 1;
+                if (stack.empty()) break;
+                cur = stack.back(); stack.pop_back();
+            } else {
+                const DNode& d = node_at(cur & REF_INDEX_MASK_INNER);
+                boxes += 2;
+                const bool near_hit = !(d.ref2 & REF_EMPTY), far_hit = !(d.ref1 & REF_EMPTY);
+                if (near_hit) {
+                    if (far_hit) stack.push_back(d.ref1);
+                    cur = d.ref2;
+                } else if (far_hit) {
+                    cur = d.ref1;
+                } else {
+                    if (stack.empty()) break;
+                    cur = stack.back(); stack.pop_back();
+                }
+            }
+        }
+        // (per-path counters are 32 bits wide in the kernels: a walk that does not fit is simply walked)
+        if (boxes < 0x10000000ull && tris < 0x10000000ull) {
+            out.nan_walk_box_tests = (uint32_t)boxes; out.nan_walk_tri_tests = (uint32_t)tris; out.nan_walk_last_tri = last;
+        } else {
+            out.nan_walk_box_tests = out.nan_walk_tri_tests = 0xFFFFFFFFu;
+        }
+    }
     return PTMI_OK;
 }
 
@@ -292,9 +329,9 @@ extern "C" int ptmi_validate_scene(const ptmi_config* config, const ptmi_scene* 
     ptmi_internal::Relayout lay;
     std::string err;
     const int rc = ptmi_internal::build_layout(*config, scene, lay, err);
-    if (rc == PTMI_OK && !lay.literal_kernel_reason.empty() && config->super_sampling) {
-        ptmi_internal::set_global_error("SUPER_SAMPLING needs the wavefront kernel, which cannot reproduce the reference on this scene: " +
-                                        lay.literal_kernel_reason);
+    if (rc == PTMI_OK && !lay.literal_kernel_reason.empty() && config->super_sampling && config->sampler == PTMI_SAMPLER_RANDOM) {
+        ptmi_internal::set_global_error("SUPER_SAMPLING needs the wavefront kernel, which cannot reproduce the reference on this scene with "
+                                        "the RANDOM sampler: " + lay.literal_kernel_reason);
         return PTMI_ERR_UNSUPPORTED;
     }
     if (rc != PTMI_OK) ptmi_internal::set_global_error(err);

@@ -25,6 +25,11 @@ struct Relayout {
     std::string literal_kernel_reason;  // scene_needs_literal_kernel()
     uint32_t root_ref = 0;
     uint32_t max_depth = 0;
+    // What a closest-hit query makes of a ray whose direction is not a number in ANY component (every comparison of the box
+    // test and of the triangle test is false: every non-empty box is "hit", every triangle accepted): it walks the whole tree
+    // in one fixed order and returns its LAST triangle.  The walk's box tests, triangle tests and last triangle (a record
+    // index; 0xFFFFFFFF: the walk meets no triangle), so that the literal loops can skip it (ptmi_literal_path.hpp).
+    uint32_t nan_walk_box_tests = 0, nan_walk_tri_tests = 0, nan_walk_last_tri = 0xFFFFFFFFu;
 };
 
 // Returns PTMI_OK or an error code with its message in `err`.  cfg: lights_size and sampler are read.

@@ -910,6 +910,27 @@ def fuzz_scene(seed, width, height, n_lights=1, hostile=False):
                  name=f"fuzz{seed}" + ("h" if hostile else "") + f"_l{n_lights}", meta={"seed": int(seed)})
 
 
+def add_zero_area_triangles(scene, k, seed=5):
+    """`k` zero-area triangles as the importer emits them for a degenerate face of a mesh (three collinear vertices pass its
+    ordering ASSERT; N = normalize(0) = 0/0, MayaImporter.cpp:943-1047) scattered through the scene's volume, appended to a COPY of
+    the scene (no tree: call bvh_create).  Coordinates with few mantissa bits, so that a, a + e, a + 2e are EXACTLY collinear in
+    float and the cross product is exactly zero."""
+    import copy
+    import warnings
+    rs = np.random.RandomState(seed)
+    lo, hi = scene.triangulation["S1"][:, :3].min(0), scene.triangulation["S1"][:, :3].max(0)
+    a = (np.round(rs.uniform(lo * 0.8, hi * 0.8, (k, 3)) * 16) / 16).astype(f32)
+    e = (np.round(rs.uniform(0.01, 0.06, (k, 3)) * 256) / 256).astype(f32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bad = triangle_create(a, a + e, a + 2 * e, mat_pos=0)
+    out = copy.copy(scene)
+    out.triangulation = _concat_tris([scene.triangulation, bad])
+    out.bvh = None
+    out.name = scene.name + f"+{k}za"
+    return out
+
+
 def corrupt_records(scene, seed):
     """What the arrays can hold although no importer writes it - the integrator takes raw records (the scene-cache files,
     any host that fills GlobalVars itself), and whatever the reference makes of them is the contract: geometric normals that

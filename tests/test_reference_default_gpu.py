@@ -323,6 +323,32 @@ def test_scenes_with_nan_distances_run_the_nan_safe_wavefront_kernel(monkeypatch
         render_scene(wild, w, h, d, 2, flags=DA, super_sampling=True, sampler=S.RANDOM)
 
 
+def test_nan_rays_skip_the_walk_over_the_whole_tree(monkeypatch):
+    """A path whose FINAL hit is a zero-area triangle shades with NaNs and scatters a ray whose direction is NaN in every
+    component; the reference then "hits" every box and accepts every triangle - comparisons only - ten walks over the whole tree.
+    The literal loops (the one-path-per-lane kernel, and what re-traces the wavefront kernel's given-up paths) add the walk's
+    counts, which the upload has taken once, and make only the walk's LAST triangle test for real: images (NaN bits included),
+    counts, histograms and totals equal the walked ones (PTMI_WALK_NAN_RAYS) and the reference kernel's, both builds."""
+    case, w, h, d, spp = "tris20k_96x64_d6", 96, 64, 6, 8
+    if not (O.have_ref_kernel(case) and O.have_ref_kernel(case, strict=True)):
+        O.missing_reference("oracle/_ref code objects not present")
+    sc = bvh_create(scenes.add_zero_area_triangles(scenes.build("tris20k", w, h), 400))
+    for flags, strict in ((DA, False), (0, True)):
+        ref = O.ref_gpu_render(case, sc, w, h, d, spp, strict=strict)
+        for kernel in (0, backend.FLAG_MEGAKERNEL):
+            ours = render_scene(sc, w, h, d, spp, flags=flags | kernel)
+            # (the scene tests what it should: whole-tree walks dominate the counts - 20,400 triangles, ~3 queries per path)
+            assert ours[3]["triangle_tests"] > 5000 * ours[3]["paths"], ours[3]
+            _assert_equal_to_reference(ours, ref, f"closed form, kernel flags {kernel}, strict {strict}")
+            monkeypatch.setenv("PTMI_WALK_NAN_RAYS", "1")
+            walked = render_scene(sc, w, h, d, spp, flags=flags | kernel)
+            monkeypatch.delenv("PTMI_WALK_NAN_RAYS")
+            assert ours[3] == walked[3] and np.array_equal(ours[0].view(np.uint32), walked[0].view(np.uint32))
+    o = O.oracle_render(sc, w, h, d, 2, default_arithmetic=True)
+    ours = render_scene(sc, w, h, d, 2, flags=DA)
+    assert np.array_equal(ours[0].view(np.uint32), o[0].view(np.uint32)) and ours[3] == o[3]
+
+
 def test_super_sampling_on_a_scene_with_nan_distances():
     """SUPER_SAMPLING (wavefront kernel only) on a scene with zero-area triangles - refused before round 4 - equals the reference
     kernel built -D SUPER_SAMPLING with its own options: images, sampling-density map and histograms."""

@@ -28,9 +28,10 @@ def test_valid_scenes_pass_and_messages_name_the_record(built):
         validate_scene(sc, 64, 64, 8)
     assert e.value.code == -5
     hostile = bvh_create(scenes.build("fuzz5h_l1", 64, 64))
-    validate_scene(hostile, 64, 64, 8)  # rendered by the one-path-per-lane kernel: still a valid scene
-    with pytest.raises(PtmiError, match="SUPER_SAMPLING") as e:
-        validate_scene(hostile, 64, 64, 8, super_sampling=True)
+    validate_scene(hostile, 64, 64, 8)  # NaN-distance records: the wavefront kernel's NANSAFE instantiation - still a valid scene,
+    validate_scene(hostile, 64, 64, 8, super_sampling=True)  # with SUPER_SAMPLING too (round 4) ...
+    with pytest.raises(PtmiError, match="SUPER_SAMPLING") as e:  # ... unless the sampler is RANDOM (nothing staged: one-path-per-lane kernel)
+        validate_scene(hostile, 64, 64, 8, sampler=1, super_sampling=True)
     assert e.value.code == -7
 
 

@@ -81,20 +81,7 @@ def without_bad_records(sc):
 
 
 def with_zero_area_triangles(sc, k, seed=5):
-    """`k` zero-area triangles as the importer emits them (three collinear vertices: N = 0/0, MayaImporter.cpp:943-1047 via
-    scenes.triangle_create) scattered through the scene's volume: what a real imported mesh brings along."""
-    rs = np.random.RandomState(seed)
-    lo, hi = sc.triangulation["S1"][:, :3].min(0), sc.triangulation["S1"][:, :3].max(0)
-    # (coordinates with few mantissa bits: a, a + e, a + 2e are then EXACTLY collinear in float, so the cross product is 0)
-    a = (np.round(rs.uniform(lo * 0.8, hi * 0.8, (k, 3)) * 16) / 16).astype(np.float32)
-    e = (np.round(rs.uniform(0.01, 0.06, (k, 3)) * 256) / 256).astype(np.float32)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        bad = scenes.triangle_create(a, a + e, a + 2 * e, mat_pos=0)
-    out = copy.copy(sc)
-    out.triangulation = scenes._concat_tris([sc.triangulation, bad])
-    out.bvh = None
-    return pt.bvh_create(out)
+    return pt.bvh_create(scenes.add_zero_area_triangles(sc, k, seed))
 
 
 def reference_rate(sc):
