@@ -155,6 +155,15 @@ typedef struct ptmi_invariant_checks {
     uint64_t negative_direct_radiance; /* :951 "Scene_ComputeDirectIllumination incorrect radiance L" */
     uint64_t scattered_below_surface;  /* header.cl:243 "Vector_PutInSameHemisphereAs": dot(out, N) > 0 */
     uint64_t statistics_out_of_range;  /* :1325,1330 "global__rayIntersectionBBx / Tri to large": >= 5000 tests on one path */
+    /* NOT a check of the reference: bounces whose result the reference's SOURCE leaves undefined.  Its water material refracts
+     * when random() >= the Fresnel fraction (FullKernel.cl:836-843); on total internal reflection the fraction is 1 and
+     * Material_FresnelWaterReflectionFraction has returned (:237) BEFORE writing refractionDirection and refractionMultCoeff
+     * (:249-251) - and random() returns exactly 1.0 for the 64 seeds nearest 2^31 (header.cl:246-253), so about one interior
+     * water hit in 10^8 refracts along an uninitialised direction with an uninitialised factor (the compiled kernel reads
+     * whatever its registers hold: stale values of other variables).  The integrator takes a zero direction and the factor
+     * n2^2/n1^2 there.  Such a path is the one thing that may differ from the reference kernel's image; counted so that a
+     * comparison can tell (tools/north_star_full_size.py). */
+    uint64_t refraction_undefined_in_reference;
 } ptmi_invariant_checks;
 
 /* ---- lifecycle ---------------------------------------------------------- */

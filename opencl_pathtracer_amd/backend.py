@@ -79,7 +79,7 @@ class SchedulerStats(C.Structure):
 USER_SNAPSHOT_SLOTS = 64  # ptmi.h: PTMI_MAX_SNAPSHOT_SLOTS - 1 (the last slot is the library's own)
 class InvariantChecks(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("sample_out_of_range", "normal_not_facing_ray", "negative_direct_radiance",
-                                         "scattered_below_surface", "statistics_out_of_range")]
+                                         "scattered_below_surface", "statistics_out_of_range", "refraction_undefined_in_reference")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -823,8 +823,11 @@ __global__ void __launch_bounds__(kWfBlock, WAVES ? WAVES : (PLAIN ? PTMI_WF_MIN
                         r.d = cam_d;
                         V4 out;
                         V4 out_normal = v4(0, 0, 0, 0);
-                        radiance = radiance + scatter_direction(r, seed, in_water, sf, gathered, transfer, out, STATS ? &out_normal : nullptr);
+                        bool undefined_in_reference = false;
+                        radiance = radiance + scatter_direction(r, seed, in_water, sf, gathered, transfer, out, STATS ? &out_normal : nullptr,
+                                                                STATS ? &undefined_in_reference : nullptr);
                         check(dot(out, out_normal) > 0.0f, C_CHK_HEMISPHERE);  // header.cl:243
+                        check(!undefined_in_reference, C_UNDEF_REFRACTION);      // (not a check of the reference: see ptmi_invariant_checks)
                         r.o = mad(out, 0.001f, hit.point);  // :880 uses the un-normalised direction
                         reflection++;
                         shadow = false;

@@ -1297,6 +1297,7 @@ int ptmi_get_invariant_checks(ptmi_ctx* ctx, ptmi_invariant_checks* out)
     out->sample_out_of_range = h[C_CHK_SAMPLE]; out->normal_not_facing_ray = h[C_CHK_NORMALS];
     out->negative_direct_radiance = h[C_CHK_RADIANCE]; out->scattered_below_surface = h[C_CHK_HEMISPHERE];
     out->statistics_out_of_range = h[C_CHK_STATS_RANGE];
+    out->refraction_undefined_in_reference = h[C_UNDEF_REFRACTION];
     return PTMI_OK;
 }
 

@@ -469,12 +469,18 @@ __device__ __forceinline__ V4 sky_color(const ptmi_sky& sky, const ptmi_uchar4* 
 // Fresnel core shared by FullKernel.cl:192-217 (glass), :219-254 (water), :256-292 (varnish)
 // `n2` is a run-time value in the water function (selected by isInWater, cl:223-232) and a literal in the glass and varnish
 // functions: the default arithmetic divides differently by the two (see fdiv), hence the divisor type.
+// `total` (optional): set when the function returns on total reflection, i.e. BEFORE the reference writes its refraction outputs
+// (cl:237 against :249-251) - see scatter_direction.
 template <class Divisor>
-__device__ __forceinline__ float fresnel_fraction(float n1, float n2, const Divisor& by_n2, float cos1, V4 incident, V4 N, V4* refr)
+__device__ __forceinline__ float fresnel_fraction(float n1, float n2, const Divisor& by_n2, float cos1, V4 incident, V4 N, V4* refr,
+                                                  bool* total = nullptr)
 {
     const float sin1 = fsqrt(mad(-cos1, cos1, 1));  // cl:202,235,275 `1 - cos1 * cos1`
     const float sin2 = fdiv(n1 * sin1, by_n2);
-    if (sin2 >= 1) return 1;
+    if (sin2 >= 1) {
+        if (total) *total = true;
+        return 1;
+    }
     const float cos2 = fsqrt(mad(-sin2, sin2, 1));
     const float r_para = fdiv(mad(n2, cos1, -(n1 * cos2)), mad(n2, cos1, n1 * cos2));  // cl:208
     const float r_perp = fdiv(mad(n1, cos1, -(n2 * cos2)), mad(n1, cos1, n2 * cos2));  // cl:209

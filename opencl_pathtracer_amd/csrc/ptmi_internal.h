@@ -105,6 +105,7 @@ enum CounterSlot {
     C_CHK_RADIANCE,    // cl:951   the light gathered at a hit is non-negative
     C_CHK_HEMISPHERE,  // h:243    the scattered direction lies in the hemisphere of its normal after Vector_PutInSameHemisphereAs
     C_CHK_STATS_RANGE, // cl:1325,1330  a path's box / triangle test count fits the 5000-bin histograms
+    C_UNDEF_REFRACTION, // cl:836-843 after :237  a totally reflected ray refracted (random() == 1.0): undefined in the reference's source
     // surface hits on a material with a file texture (STATS builds): the texel term of SURVEY 8d's algorithmic bytes
     C_TEXTURED_HITS,
     // paths a wavefront launch gave up (a ray that is not a number) and the literal loops traced again (every build)

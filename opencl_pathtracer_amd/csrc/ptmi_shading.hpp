@@ -48,8 +48,13 @@ __device__ __forceinline__ void load_surface(const SceneT& sc, const Ray& r, con
 // isInWater; returns the radiance gathered at this bounce.
 // (split in two so that a caller with several sources of new rays can share ONE copy of the ray set-up, which holds
 // four divisions: scatter_direction = everything up to the outgoing direction `out`, un-normalised as :880 uses it)
+// `undefined_in_reference` (statistics builds): set when the bounce is one the reference's SOURCE leaves undefined - the water
+// material refracting a totally reflected ray, which needs random() == 1.0 exactly: Material_FresnelWaterReflectionFraction has
+// then returned before writing the refraction direction and factor that cl:836-843 go on to read.  Here: a zero direction (which
+// Vector_PutInSameHemisphereAs turns into 0.01 * N) and the factor n2^2 / n1^2.
 __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& in_water, const Surface& sf, V4 direct,
-                                                V4& transfer, V4& out_direction, V4* hemisphere_normal = nullptr)
+                                                V4& transfer, V4& out_direction, V4* hemisphere_normal = nullptr,
+                                                bool* undefined_in_reference = nullptr)
 {
     V4 N = r.d;
     V4 radiance = v4(0, 0, 0, 0);
@@ -74,11 +79,13 @@ __device__ __forceinline__ V4 scatter_direction(const Ray& r, int& seed, bool& i
     } else if (type == PTMI_MAT_WATER) {
         V4 refracted = v4(0, 0, 0, 0);
         const float n1 = in_water ? kNWater : 1.f, n2 = in_water ? 1.f : kNWater;
-        const float f = fresnel_fraction(n1, n2, n2, -dot(r.d, sf.Ns), r.d, sf.Ns, &refracted);
+        bool total = false;
+        const float f = fresnel_fraction(n1, n2, n2, -dot(r.d, sf.Ns), r.d, sf.Ns, &refracted, undefined_in_reference ? &total : nullptr);
         if (lcg_random(seed) < f) {
             out = reflect_about(r.d, sf.Ns);
             N = sf.Ng;
         } else {
+            if (undefined_in_reference && total) *undefined_in_reference = true;
             in_water = !in_water;
             out = refracted;
             N = -sf.Ng;

@@ -680,9 +680,14 @@ static float fresnel_glass(f4 incident, f4 N)
 }
 
 /* Material_FresnelWaterReflectionFraction, cl:219-254.  On total reflection the
- * reference returns before writing its outputs; callers only read them in the
- * refraction branch, which needs random < 1 ... which random()==1.0 excludes
- * too, so the uninitialised values are never consumed. */
+ * reference returns (cl:237) before writing its outputs (cl:249-251); its caller
+ * reads them in the refraction branch (cl:836-843), which is taken when
+ * random() >= 1 - and random() returns exactly 1.0 for the 64 seeds nearest 2^31.
+ * So about one interior water hit in 10^8 consumes UNINITIALISED values: undefined
+ * in the reference's source (its compiled kernel reads stale registers).  This
+ * checker and the integrator agree on a zero direction and the factor n2^2/n1^2
+ * there (the caller's initial values / fresnel_water's own computation); round 4
+ * found the one such path in 531 M of the configs[4] stand-in. */
 static float fresnel_water(f4 incident, f4 N, int already_in_water, f4* refraction_dir, float* mult)
 {
     float n1, n2, f;

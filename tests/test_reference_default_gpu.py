@@ -134,6 +134,39 @@ def test_full_size_bit_exact_vs_reference_default_build(case):
     _assert_equal_to_reference(render_scene(sc, w, h, d, spp, sampler=sampler, flags=DA), ref, case)
 
 
+def test_the_one_bounce_the_reference_leaves_undefined():
+    """The reference's water material refracts when random() >= its Fresnel fraction (cl:836-843).  On total internal reflection
+    that fraction is 1 and Material_FresnelWaterReflectionFraction has returned (cl:237) BEFORE it writes the refraction direction
+    and factor (cl:249-251) - and random() returns exactly 1.0 for the 64 seeds nearest 2^31 (header.cl:246-253: the float
+    conversion rounds them up).  So one interior water hit in ~10^8 refracts along an UNINITIALISED direction with an uninitialised
+    factor: undefined in the reference's source; its compiled kernel reads stale registers.  The configs[4] stand-in
+    at full size holds one such path in its first 64 iterations - pixel (3075, 393), iteration 25 - found by round 4's full-size
+    comparison: that pixel is the ONLY difference from the reference kernel in that iteration, the statistics build counts exactly
+    that one bounce, and the oracle agrees with the integrator about it."""
+    case, w, h, d, it = "mayalike_3840x2160_d16", 3840, 2160, 16, 25
+    if not O.have_ref_kernel(case):
+        O.missing_reference("oracle/_ref code object not present")
+    sc = bvh_create(scenes.build("mayalike", w, h))
+    ref = O.ref_gpu_render(case, sc, w, h, d, 1, first_iteration=it)
+    ours = render_scene(sc, w, h, d, 1, first_iteration=it, flags=DA)
+    bad = np.argwhere((ours[0].view(np.uint32) != ref[0].view(np.uint32)).any(-1))
+    assert bad.tolist() == [[393, 3075]], bad[:8].tolist()
+    assert np.array_equal(ours[1], ref[1])
+    be = backend.Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, flags=DA | backend.FLAG_SCHEDULER_STATS)
+    try:
+        be.initialize_memory(sc)
+        be.render(it, 1)
+        be.synchronize()
+        checks = be.invariant_checks()
+        stats_image, _ = be.read_image()
+    finally:
+        be.release()
+    assert checks["refraction_undefined_in_reference"] == 1, checks
+    assert np.array_equal(stats_image.view(np.uint32), ours[0].view(np.uint32))
+    _, o_radiance = O.oracle_trace(sc, w, h, d, 3075, 393, it, default_arithmetic=True)
+    assert np.array_equal(np.asarray(o_radiance, np.float32).view(np.uint32), ours[0][393, 3075].view(np.uint32))
+
+
 def test_four_million_triangles_bit_exact_vs_reference_default_build():
     """A tree of depth 24 (4M random triangles, 427 MB of records: four workgroups per CU instead of five, leaves and nodes far
     beyond the L2s) through the same comparison: the reference's code object is specialised on sampler, image size, ray depth and
