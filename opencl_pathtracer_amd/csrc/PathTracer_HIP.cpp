@@ -184,6 +184,10 @@ static void report_invariant_checks(const GlobalVars& globalVars)
                          "incorrect radiance L %llu, Vector_PutInSameHemisphereAs %llu, rayIntersection histogram overflow %llu\n",
                  (unsigned long long)c.sample_out_of_range, (unsigned long long)c.normal_not_facing_ray, (unsigned long long)c.negative_direct_radiance,
                  (unsigned long long)c.scattered_below_surface, (unsigned long long)c.statistics_out_of_range);
+    if (c.refraction_undefined_in_reference)
+        std::fprintf(stderr, "[ptmi] %llu bounce(s) the reference's source leaves undefined (FullKernel.cl:836-843 after :237: a totally reflected ray "
+                             "refracted, random() == 1.0): rendered with a zero refraction direction\n",
+                     (unsigned long long)c.refraction_undefined_in_reference);
 }
 
 void OpenCL_RunKernel(GlobalVars& globalVars, bool (*UpdateWindowFunc)(void), uint numImagesToRender,

@@ -542,7 +542,7 @@ def test_scheduler_statistics_and_the_leaf_pass_item_protocol(flags, scene_facto
     assert st["leaf_item_violations"] == 0
     # the reference's -D LOG_INFO device-side checks (header.cl:21-48), counted by this build: a clean render
     assert be_checks == {"sample_out_of_range": 0, "normal_not_facing_ray": 0, "negative_direct_radiance": 0,
-                         "scattered_below_surface": 0, "statistics_out_of_range": 0}
+                         "scattered_below_surface": 0, "statistics_out_of_range": 0, "refraction_undefined_in_reference": 0}
     assert st["trips_node"] > 0 and st["trips_triangle"] > 0 and st["trips_path"] > 0
     # every counted triangle test was one item of one pass (a shadow query stops COUNTING at its first hit: items dealt out
     # behind it in the same pass are tested and not counted)
