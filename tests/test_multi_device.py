@@ -199,6 +199,23 @@ def test_eight_listed_devices_equal_the_single_context(scene_factory):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene,w,h,d", [("tris1m", 1920, 1080, 10), ("mayalike", 3840, 2160, 16)], ids=["configs3", "configs4"])
+def test_eight_listed_devices_on_the_baseline_workloads(scene, w, h, d):
+    """BASELINE configs[3] and configs[4] are eight-GPU jobs: their SCENES at their SIZES through the eight-device control flow
+    (one GPU listed eight times: eight scene replicas, eight stage sets, eight partial images of 41 / 166 MB summed on
+    devices[0] in device order), 16 iterations = two per device, in the reference's own arithmetic: counts, histograms and
+    counters equal the single-context render exactly, the image up to the order of the float additions."""
+    from opencl_pathtracer_amd import scenes, bvh_create
+    sc = bvh_create(scenes.build(scene, w, h))
+    flags = backend.FLAG_DEFAULT_ARITHMETIC
+    color, count, stats, counters = render_scene(sc, w, h, d, 16, flags=flags)
+    c8, n8, s8, k8 = render_scene(sc, w, h, d, 16, flags=flags, devices=[0] * 8)
+    assert np.array_equal(n8, count) and k8 == counters and all(np.array_equal(a, b) for a, b in zip(stats, s8))
+    assert np.allclose(c8, color, rtol=4e-6, atol=1e-6)
+    assert (cases.rms_per_channel(c8, n8, color, count) <= 1e-6).all()
+
+
+@pytest.mark.gpu
 def test_rccl_reduce_behind_the_c_abi(scene_factory, monkeypatch):
     """The collective north_star names, reached through the reference API's readback: PTMI_REDUCE=rccl-always sends the image of
     a (one-device) context through librccl's ncclReduce - loaded at run time, one-rank communicator from ncclCommInitAll, on the
