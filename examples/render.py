@@ -20,7 +20,7 @@ import opencl_pathtracer_amd as pt  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--scene", default="cornell", help="cornell | matmix | tris<N>[k|m] (opencl_pathtracer_amd.scenes.build)")
+    ap.add_argument("--scene", default="cornell", help="cornell | mayalike | matmix | tris<N>[k|m] (opencl_pathtracer_amd.scenes.build)")
     ap.add_argument("--obj", help="a Wavefront OBJ file instead of a built-in scene (opencl_pathtracer_amd.obj_import)")
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=512)
