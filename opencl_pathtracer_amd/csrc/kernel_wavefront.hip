@@ -1059,6 +1059,10 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
         if (slot < n_slots) {
             const uint4 v = reinterpret_cast<const uint4*>(stage)[slot];
             marked = v.x == kPoisonMarker && v.y == kPoisonMarker && v.z == kPoisonMarker && v.w == kPoisonMarker;
+            // ... and the path counted nothing (a given-up path restarts its counters): a radiance that merely CARRIES the
+            // marker's bits - NaN payloads a caller put into a light or a material colour - belongs to a path that has made at
+            // least one box or triangle test
+            if (marked && stage_stats != nullptr) marked = stage_stats[slot] == pack_path_statistics(0u, 0u, 0u);
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(marked);
         if (m == 0ull) continue;
