@@ -60,7 +60,13 @@
 
 namespace PTMI_DEV_NS {
 
-constexpr int kWfBlock = 256;
+constexpr int kWfBlock = 256;  // lanes per workgroup: trees of up to 22 levels (five workgroups = twenty waves per CU)
+// ... and for deeper trees (BLOCK template argument): the LDS a workgroup needs - (depth + 9) KB per 256 lanes - is then handed
+// out in quarters, so that a CU whose 160 KB hold FOUR wide workgroups (16 waves; 23 to 27 levels) holds 17-19 narrow ones.
+// Measured on MI355X, same box, Msamples/s, workgroups of 256 / 128 / 64 lanes: configs[4] stand-in (general shading, depth 23)
+// 1240 / 1299 / 1301; 4M triangles (plain, depth 24) in profiles/r04_ab_workgroup_size.txt; 1M triangles (plain, depth 22: twenty
+// waves either way) 976 / 931 / 938 - so the narrow form is only launched where the wide one does not get its five workgroups.
+constexpr int kWfBlockNarrow = 64;
 constexpr int kWfStack = PTMI_BVH_MAX_DEPTH;
 #ifndef PTMI_WF_WAIT_DEBT
 // lane-trips of waiting a wave tolerates before it spends a pass on path logic: a launch parameter (DWarm::wait_debt),
@@ -128,7 +134,7 @@ static_assert(!kLeafPass || kHitWords == 4, "leaf passes write the 4-word closes
 // a pass (up to 64 triangles, one per lane) runs when this many lanes wait at a leaf (3 triangles each on average), or when
 // the waiting triangles are kLeafRatio times as many as the lanes left to take node steps
 constexpr int kLeafLanes = PTMI_WF_LEAF_LANES, kLeafRatio = PTMI_WF_LEAF_RATIO;
-constexpr int kLeafPassWords = kLeafPass ? 4 * kWfBlock : 0;  // LDS: one 64-bit key per lane + 64 items of 8 bytes per wave
+constexpr int kLeafPassWordsPerLane = kLeafPass ? 4 : 0;  // LDS: one 64-bit key per lane + 64 items of 8 bytes per wave
 #ifndef PTMI_WF_TOS
 // The top entry of a lane's traversal stack ALSO in a register (round 4): a pop takes the register and the LDS read that refills
 // it is not needed before the lane's NEXT pop, instead of an LDS round trip on the critical path of every node step.
@@ -214,14 +220,9 @@ __device__ __forceinline__ void decode_leaf(const DWarm& sc, uint32_t ref, uint3
 // ray is not a number, and redo_poisoned_kernel traces it again with the literal loops.  Everything else - and every path that
 // never reaches such a record - is the ordinary kernel.  (A shadow query needs nothing: it ends at the FIRST accepted triangle
 // in index order whatever the distances are, and its limit never changes.)  Clean scenes run the instantiations without it.
-// WAVES (0 = the default of the kind): the waves per SIMD the register allocator must fit.  Trees of 23 levels and more need
-// 32 KB of LDS per workgroup and more, so a CU holds FOUR workgroups of them whatever the registers allow; the general shading
-// instantiation is then also built for four waves (128 registers, no spilled register instead of 30) and that build is launched
-// where the occupancy query says the five-wave one gets four anyway: configs[4] stand-in (depth 23) 1209 -> 1239 Msamples/s, same
-// box.  (At five workgroups per CU the four-wave build loses 9 %: 974 -> 889 on the 1M-triangle scene.  The plain kernel gains
-// nothing from it on the 4M-triangle scene, depth 24: 516.6 / 517.0.)
-template <bool STATS, bool PRE, bool SS, bool PLAIN = false, bool NANSAFE = false, int WAVES = 0>
-__global__ void __launch_bounds__(kWfBlock, WAVES ? WAVES : (PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN_WAVES_GENERAL)) render_wavefront_kernel(
+// BLOCK: lanes per workgroup (kWfBlock, or kWfBlockNarrow for deep trees: see there).
+template <bool STATS, bool PRE, bool SS, bool PLAIN = false, bool NANSAFE = false, int BLOCK = 256>
+__global__ void __launch_bounds__(BLOCK, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN_WAVES_GENERAL) render_wavefront_kernel(
                                                                     const DScene* __restrict__ scene_in_memory, const DWarm sc_arg, const uint32_t first_iteration,
                                                                     const uint32_t n_iterations, const uint32_t iteration_stride,
                                                                     const uint32_t n_jobs,
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(kWfBlock, WAVES ? WAVES : (PLAIN ? PTMI_WF_MIN
     DWarm sc = sc_arg;
     if (PLAIN) { sc.sampler = PTMI_SAMPLER_JITTERED; sc.russian_roulette = 0; sc.n_lights = 1; }  // ... and ONE light
     constexpr bool kOneLight = PLAIN;  // (nothing gathered across shadow queries, no light index: five registers fewer per lane)
+    constexpr int kWfBlock = BLOCK;  // (shadows the namespace's: every LDS stride below is the workgroup's own width)
     constexpr bool kTos = PTMI_WF_TOS == 1 || (PTMI_WF_TOS == 2 && !PLAIN);
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_mem[];
     __shared__ unsigned long long block_counters[C_COUNT];
@@ -1262,21 +1264,21 @@ static uint32_t clamp_levels(uint32_t stack_levels)
     return stack_levels;
 }
 
-static size_t wavefront_lds_bytes(uint32_t stack_levels)
+static size_t wavefront_lds_bytes(uint32_t stack_levels, int block)
 {
     stack_levels = clamp_levels(stack_levels);
-    // closest-hit record + sentinel + stack (+ the keys and items of the leaf passes)
-    return ((size_t)(stack_levels + 1 + PTMI_DEV_NS::kHitWords) * PTMI_DEV_NS::kWfBlock + PTMI_DEV_NS::kLeafPassWords) * sizeof(uint32_t);
+    // closest-hit record + sentinel + stack (+ the keys and items of the leaf passes), per lane of the workgroup
+    return (size_t)(stack_levels + 1 + PTMI_DEV_NS::kHitWords + PTMI_DEV_NS::kLeafPassWordsPerLane) * block * sizeof(uint32_t);
 }
 
 // workgroups of instantiation `kernel` the current device holds at once (the persistent grid): registers and LDS decide
 template <class Kernel>
-static int resident_blocks_of(Kernel kernel, uint32_t stack_levels)
+static int resident_blocks_of(Kernel kernel, uint32_t stack_levels, int block)
 {
     int device = 0, per_cu = 0, n_cu = 0;
     if (hipGetDevice(&device) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PTMI_DEV_NS::kWfBlock, wavefront_lds_bytes(stack_levels)) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, wavefront_lds_bytes(stack_levels, block)) != hipSuccess)
         return 0;
     if (per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
@@ -1303,9 +1305,6 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
             e = hipMemsetD32Async((hipDeviceptr_t)(job_counter + 2), (int)PTMI_DEV_NS::kGiveUpListCap, 1, (hipStream_t)stream);
     }
     if (e == hipSuccess) {
-        uint32_t blocks = (n_jobs + PTMI_DEV_NS::kWfBlock - 1) / PTMI_DEV_NS::kWfBlock;
-        const dim3 b(PTMI_DEV_NS::kWfBlock);
-        const size_t lds = wavefront_lds_bytes(stack_levels);
         const uint32_t lv = clamp_levels(stack_levels);
         hipStream_t st = (hipStream_t)stream;
         PTMI_DEV_NS::DWarm warm{};
@@ -1327,22 +1326,34 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         // the persistent grid of the chosen instantiation on the CURRENT device (instantiations differ in registers, devices in
         // CUs and partition mode, hence in workgroups held at once): asked once per (instantiation, device, stack levels);
         // host threads that drive contexts of their own may race for an entry, and then write the same value
-#define PTMI_LAUNCH_WF_IMPL(S, P, A, L, N)                                                                                \
+#define PTMI_LAUNCH_WF_BLOCK(S, P, A, L, N, B)                                                                             \
     do {                                                                                                                  \
-        auto kernel = PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L, N>;                                                 \
+        auto kernel = PTMI_DEV_NS::render_wavefront_kernel<S, P, A, L, N, B>;                                              \
         static std::atomic<int> resident_cache[kMaxCachedDevices][PTMI_BVH_MAX_DEPTH + 1];                                 \
         int resident = cached_device ? resident_cache[device][lv].load(std::memory_order_relaxed) : 0;                     \
         if (resident == 0) {                                                                                               \
-            resident = resident_blocks_of(kernel, lv);                                                                     \
+            resident = resident_blocks_of(kernel, lv, B);                                                                  \
             if (cached_device) resident_cache[device][lv].store(resident, std::memory_order_relaxed);                      \
         }                                                                                                                  \
-        uint32_t nb = blocks;                                                                                             \
+        uint32_t nb = (n_jobs + (B) - 1) / (B);                                                                           \
         if (resident > 0 && nb > (uint32_t)resident) nb = (uint32_t)resident;                                             \
-        hipLaunchKernelGGL(kernel, dim3(nb), b, lds, st, scene_in_device_memory, warm, first_iteration, n_iterations,      \
-                           iteration_stride, n_jobs, job_counter, lv, stage, stage_stats);                                \
+        hipLaunchKernelGGL(kernel, dim3(nb), dim3(B), wavefront_lds_bytes(lv, B), st, scene_in_device_memory, warm,        \
+                           first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage, stage_stats); \
     } while (0)
-#define PTMI_LAUNCH_WF(S, P, A, N)                                                                                    \
-    PTMI_LAUNCH_WF_IMPL(S, P, A, false, N)
+#define PTMI_LAUNCH_WF_IMPL(S, P, A, L, N) PTMI_LAUNCH_WF_BLOCK(S, P, A, L, N, PTMI_DEV_NS::kWfBlock)
+#define PTMI_LAUNCH_WF(S, P, A, N) PTMI_LAUNCH_WF_IMPL(S, P, A, false, N)
+        // Deep trees (23 levels and more): the wide workgroup's LDS no longer fits five times into a CU; the two production
+        // instantiations are then launched in their narrow form (kWfBlockNarrow).  Asked once per device and depth.
+        static std::atomic<int> wide_fits[kMaxCachedDevices][PTMI_BVH_MAX_DEPTH + 1];  // 0 = not asked, 1 = five wide workgroups fit, 2 = they do not
+        int fits = cached_device ? wide_fits[device][lv].load(std::memory_order_relaxed) : 0;
+        if (fits == 0) {
+            int n_cu = 0;
+            const int wide = resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, true, false>, lv, PTMI_DEV_NS::kWfBlock);
+            const bool known = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0 && wide > 0;
+            fits = known && wide < 5 * n_cu ? 2 : 1;
+            if (cached_device) wide_fits[device][lv].store(fits, std::memory_order_relaxed);
+        }
+        const bool narrow = fits == 2 && std::getenv("PTMI_WIDE_WORKGROUPS") == nullptr;  // (developer switch: A/B runs)
         // instantiations: the common case (no statistics, no adaptive sampling, records that cannot yield NaN distances) pays
         // for none of them; the statistics and SUPER_SAMPLING builds always carry the NaN check (two instructions per
         // accepted triangle)
@@ -1355,32 +1366,18 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
             else if (sc.tris_precomputed) PTMI_LAUNCH_WF(false, true, false, true);
             else PTMI_LAUNCH_WF(false, false, false, true);
         } else {
-            if (plain) PTMI_LAUNCH_WF_IMPL(false, true, false, true, false);  // the common case, BASELINE's untextured scenes among them
-            else if (sc.tris_precomputed) {
-                // deep trees: LDS holds four workgroups per CU -> the 128-register build (see WAVES); asked once per device and depth
-                static std::atomic<int> grid_of_four[kMaxCachedDevices][PTMI_BVH_MAX_DEPTH + 1];  // 0 = not asked, -1 = five fit, else its grid
-                int grid4 = cached_device ? grid_of_four[device][lv].load(std::memory_order_relaxed) : 0;
-                if (grid4 == 0) {
-                    int n_cu = 0;
-                    const int five = resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, false, false>, lv);
-                    const bool four = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0 &&
-                                      five > 0 && five < 5 * n_cu;
-                    grid4 = four ? resident_blocks_of(PTMI_DEV_NS::render_wavefront_kernel<false, true, false, false, false, 4>, lv) : -1;
-                    if (grid4 == 0) grid4 = -1;
-                    if (cached_device) grid_of_four[device][lv].store(grid4, std::memory_order_relaxed);
-                }
-                if (grid4 > 0) {
-                    uint32_t nb = blocks;
-                    if (nb > (uint32_t)grid4) nb = (uint32_t)grid4;
-                    hipLaunchKernelGGL((PTMI_DEV_NS::render_wavefront_kernel<false, true, false, false, false, 4>), dim3(nb), b, lds, st,
-                                       scene_in_device_memory, warm, first_iteration, n_iterations, iteration_stride, n_jobs, job_counter, lv, stage,
-                                       stage_stats);
-                } else PTMI_LAUNCH_WF(false, true, false, false);
+            if (plain) {  // the common case, BASELINE's untextured scenes among them
+                if (narrow) PTMI_LAUNCH_WF_BLOCK(false, true, false, true, false, PTMI_DEV_NS::kWfBlockNarrow);
+                else PTMI_LAUNCH_WF_IMPL(false, true, false, true, false);
+            } else if (sc.tris_precomputed) {
+                if (narrow) PTMI_LAUNCH_WF_BLOCK(false, true, false, false, false, PTMI_DEV_NS::kWfBlockNarrow);
+                else PTMI_LAUNCH_WF(false, true, false, false);
             }
             else PTMI_LAUNCH_WF(false, false, false, false);
         }
 #undef PTMI_LAUNCH_WF
 #undef PTMI_LAUNCH_WF_IMPL
+#undef PTMI_LAUNCH_WF_BLOCK
         e = hipGetLastError();
         if (e == hipSuccess && stage == nullptr && sc.sampler == PTMI_SAMPLER_RANDOM) {
             // RANDOM sampler: behind the launch, the paths on its give-up list (returns at once when there is none)

@@ -26,13 +26,13 @@ def resources(tree=ROOT, arithmetic=1, extra=()):
         m = re.match(r"\w+?23render_wavefront_kernelI((?:Lb[01]E)+)(?:Li(\d+)E)?E", block)
         if not m:
             continue
-        key = "".join(re.findall(r"Lb([01])E", m.group(1))) + ("w" + m.group(2) if m.group(2) not in (None, "0") else "")  # STATS PRE SS PLAIN NANSAFE [wN]
+        key = "".join(re.findall(r"Lb([01])E", m.group(1))) + ("b" + m.group(2) if m.group(2) not in (None, "256") else "")  # STATS PRE SS PLAIN NANSAFE [bN: lanes per workgroup]
         res[key] = {k.strip(): int(v) for k, v in re.findall(r"remark: [^\n]*?\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", block)}
     name, depth2 = None, False
     for line in open(out):
         m = re.match(r"\w+?23render_wavefront_kernelI((?:Lb[01]E)+)(?:Li(\d+)E)?E\w*:", line)
         if m:
-            name, depth2 = "".join(re.findall(r"Lb([01])E", m.group(1))) + ("w" + m.group(2) if m.group(2) not in (None, "0") else ""), False
+            name, depth2 = "".join(re.findall(r"Lb([01])E", m.group(1))) + ("b" + m.group(2) if m.group(2) not in (None, "256") else ""), False
             res[name]["loop"] = Counter()
         elif re.match(r"(\.LBB|; %bb\.)", line):
             depth2 = "Depth=2" in line

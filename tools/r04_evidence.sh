@@ -31,7 +31,7 @@ case $part in
     one_scene r04_tris1m ""
     echo "== strict arithmetic"; python bench.py --steps 6 --warmup 1 --arithmetic strict --no-cpu-baseline --no-boundary > gpurun_out/r04_tris1m_bench_strict.json 2> gpurun_out/r04_tris1m_bench_strict.err;;
   mayalike)
-    one_scene r04_mayalike "--general --four-waves" --scene mayalike --width 3840 --height 2160 --depth 16 --spp-per-step 25;;
+    one_scene r04_mayalike "--general --narrow" --scene mayalike --width 3840 --height 2160 --depth 16 --spp-per-step 25;;
   configs)
     bash tools/bench_configs.sh config0 config1 matmix tris4m
     echo "== north star at full sizes"; python tools/north_star_full_size.py tris1m cornell mayalike 2>&1 | grep -v "^{" | tail -8;;

@@ -4,7 +4,7 @@
 No counter of gfx950 separates the VALU instructions by what they cost their SIMD (SQ_ACTIVE_INST_VALU counts in quad-cycles,
 one per instruction: it cannot tell a 2-cycle v_fma_f32 from a 4-cycle v_pk_fma_f32).  So the cost is priced from the code:
 
-  1. the ISA of the production kernel (render_wavefront_kernel<false, true, false, true, false, 0>, the arithmetic given) is split into
+  1. the ISA of the production kernel (render_wavefront_kernel<false, true, false, true, false, 256>, the arithmetic given) is split into
      its three kinds of wave-level work - NODE TRIP, LEAF PASS (both in the depth-2 traversal loop) and PATH-LOGIC PASS (the
      depth-1 remainder of the main loop) - and every vector instruction of each is put in a cost class with the cycle costs
      tools/microbench/pk_rate.hip measured on the MI355X: 8 for transcendentals (v_rcp / v_rsq / v_sqrt / v_sin / v_cos / v_exp /
@@ -22,7 +22,7 @@ trip skips when no lane needs them, which the check in 3. bounds.
 
 usage: tools/valu_cost_model.py BENCH_JSON_WITH_SCHEDULER_STATS PMC_JSON [--arithmetic default|strict] [--general] > profiles/r04_valu_cost_model_<scene>.json
 (--general: the general shading instantiation - textures, all material and light types - instead of the plain-scene one;
- --four-waves: its 128-register build, which deep trees run)
+ --narrow: the instantiation with workgroups of 64 lanes, which deep trees run)
 """
 import json
 import os
@@ -47,14 +47,14 @@ def cost_class(op):
     return 2
 
 
-def kernel_blocks(arith, general=False, waves=0):
+def kernel_blocks(arith, general=False, block=256):
     ns = "11ptmi_dev_da" if arith == "default" else "8ptmi_dev"
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                           "-Iinclude", "-Iopencl_pathtracer_amd/csrc", f"-DPTMI_DEFAULT_ARITHMETIC={1 if arith == 'default' else 0}",
                           "--cuda-device-only", "-S", "opencl_pathtracer_amd/csrc/kernel_wavefront.hip", "-o", "-"],
                          cwd=ROOT, check=True, capture_output=True, text=True).stdout.split("\n")
     # general / plain-scene shading (what the workload's launches pick); <STATS, PRE, SS, PLAIN, NANSAFE>
-    tag = f"ILb0ELb1ELb0ELb0ELb0ELi{waves}EE" if general else "ILb0ELb1ELb0ELb1ELb0ELi0EE"
+    tag = f"ILb0ELb1ELb0ELb{0 if general else 1}ELb0ELi{block}EE"
     start = next(i for i, l in enumerate(asm) if l.startswith(f"_ZN{ns}23render_wavefront_kernel{tag}"))
     end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
     blocks, cur = [], None
@@ -86,8 +86,8 @@ def main():
     pmc = json.load(open(sys.argv[2]))
     arith = sys.argv[sys.argv.index("--arithmetic") + 1] if "--arithmetic" in sys.argv else bench.get("arithmetic", "default")
     general = "--general" in sys.argv
-    waves = 4 if "--four-waves" in sys.argv else 0  # (the 128-register build of the general kernel: trees of 23 levels and more)
-    blocks = kernel_blocks(arith, general, waves)
+    block = 64 if "--narrow" in sys.argv else 256  # (workgroups of 64 lanes: what trees of 23 levels and more run)
+    blocks = kernel_blocks(arith, general, block)
     loop2 = [b for b in blocks if b["depth"] == 2]
     # the traversal loop holds the node trip first, then the leaf pass: the pass starts at the block that builds the item
     # numbering (the only v_mbcnt of the loop) - the block before it is its scalar "is a pass due" test
@@ -107,7 +107,7 @@ def main():
     v = lambda k: pmc[k]["per_launch_mean"]
     cycles = v("GRBM_GUI_ACTIVE") / 8.0
     measured_n = v("SQ_INSTS_VALU")
-    out = {"kernel": f"render_wavefront_kernel<false,true,false,{'false' if general else 'true'},false,{waves}> ({arith} arithmetic)", "workload": bench["config"]["workload"],
+    out = {"kernel": f"render_wavefront_kernel<false,true,false,{'false' if general else 'true'},false,{block}> ({arith} arithmetic)", "workload": bench["config"]["workload"],
            "cycle_costs": "tools/microbench/pk_rate.hip on MI355X: 2 plain 32-bit, 4 packed fp32 / 64-bit / min3-max3 / compares / lane ops, 8 transcendental",
            "static_per_trip": regions, "trips_per_launch": w,
            "predicted_valu_instructions_per_launch": pred_n, "measured_SQ_INSTS_VALU_per_launch": measured_n,
