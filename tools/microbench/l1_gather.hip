@@ -67,10 +67,44 @@ __global__ void __launch_bounds__(256, 5) gather(const float4* __restrict__ recs
     if ((threadIdx.x & 63u) == 0) atomicAdd(quads_read, q);
 }
 
+// --cooperative 1: the same 64 records per wave and round, but FOUR LANES SHARE A RECORD - lane l reads quad (l & 3) of the record of
+// its group of four, in four instructions for four records: every dwordx4 instruction of the wave touches 16 lines instead of 64.
+// (Does the L1 charge per lane or per line?  If per line, a traversal that fetched its records this way and handed the quads round
+// through the LDS would quadruple the ceiling.)
+__global__ void __launch_bounds__(256, 5) gather_cooperative(const float4* __restrict__ recs, uint32_t n_cold, uint32_t n_hot, uint32_t miss_permille,
+                                                             int iters, float* out, unsigned long long* quads_read)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t quad = tid & 3u;
+    uint32_t s = tid * 2654435761u + 12345u;
+    float acc = 0.f;
+    uint32_t quads = 0;
+    for (int it = 0; it < iters; it++) {
+        // every lane draws ONE record, as in the other form (same index arithmetic per record) ...
+        s = s * 1664525u + 1013904223u;
+        const uint32_t r = (s >> 8) + (__float_as_uint(acc) & 1u);
+        const bool cold = (r % 1000u) < miss_permille;
+        const uint32_t idx = cold ? n_hot + (r / 7u) % n_cold : (r / 7u) % n_hot;
+        // ... and the four lanes of a group fetch their four records together: instruction u reads the record of the group's lane u
+        float4 a[4];
+        a[0] = recs[(size_t)__builtin_amdgcn_update_dpp(0u, idx, 0x00, 0xf, 0xf, false) * 4 + quad];
+        a[1] = recs[(size_t)__builtin_amdgcn_update_dpp(0u, idx, 0x55, 0xf, 0xf, false) * 4 + quad];
+        a[2] = recs[(size_t)__builtin_amdgcn_update_dpp(0u, idx, 0xaa, 0xf, 0xf, false) * 4 + quad];
+        a[3] = recs[(size_t)__builtin_amdgcn_update_dpp(0u, idx, 0xff, 0xf, 0xf, false) * 4 + quad];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += a[u].x + a[u].w;
+        quads += 4u;
+    }
+    out[tid] = acc;
+    unsigned long long q = quads;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_down(q, o);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(quads_read, q);
+}
+
 int main(int argc, char** argv)
 {
     uint32_t n_cold = 1665533u, n_hot = 64u, miss = 600u, late = 570u;
-    int iters = 2000, waves = 5, only_u = 0;
+    int iters = 2000, waves = 5, only_u = 0, cooperative = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--cold-records")) n_cold = (uint32_t)atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--hot-records")) n_hot = (uint32_t)atoi(argv[i + 1]);
@@ -79,6 +113,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--waves-per-simd")) waves = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--in-flight")) only_u = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--cooperative")) cooperative = atoi(argv[i + 1]);
         else { printf("unknown option %s\n", argv[i]); return 2; }
     }
     hipDeviceProp_t prop;
@@ -94,6 +129,27 @@ int main(int argc, char** argv)
     CHECK(hipMemcpy(recs, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    if (cooperative) {
+        float best = 1e30f;
+        unsigned long long q = 0;
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipMemset(quads, 0, 8));
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(gather_cooperative, dim3(blocks), dim3(256), 0, 0, recs, n_cold, n_hot, miss, iters, out, quads);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+            CHECK(hipMemcpy(&q, quads, 8, hipMemcpyDeviceToHost));
+        }
+        const double n_rec = (double)blocks * 256 * iters;  // 64 records per wave and round, as in the other form
+        printf("{\"cooperative\": 1, \"in_flight_per_lane\": 1, \"waves_per_simd\": %d, \"hot_records\": %u, \"cold_records\": %u, \"miss_permille\": %u, "
+               "\"late_permille\": 1000, \"ms\": %.3f, \"G_records_per_s\": %.2f, \"quads_per_record\": %.3f, \"G_lane_accesses_per_s\": %.2f, "
+               "\"lane_accesses_per_clk_per_CU_at_2.4GHz\": %.3f, \"CUs\": %d}\n",
+               waves, n_hot, n_cold, miss, best, n_rec / best / 1e6, (double)q / n_rec, (double)q / best / 1e6,
+               (double)q / (best * 1e-3) / 2.4e9 / prop.multiProcessorCount, prop.multiProcessorCount);
+        return 0;
+    }
     for (int u : {1, 2, 4}) {
         if (only_u && u != only_u) continue;
         float best = 1e30f;
