@@ -465,23 +465,28 @@ def reference_kernel_leg(pt, scene, args, W, H, D, device, flags, batched_mpaths
     O.ref_gpu_render(case, scene, W, H, D, 1, first_iteration=7)  # warm-up: module load, clocks
     _, _, _, ms = O.ref_gpu_render(case, scene, W, H, D, n_it)
     ref_mpaths = W * H * n_it / ms / 1e3
-    # the integrator launched the same way: one iteration per launch and a wait after every launch.  Twice: as the library
-    # serves such a caller by default - once it has seen the caller come back for the next image it keeps the launches of the
-    # next two calls in flight (ptmi_api.cpp: render_on_device, PTMI_RENDER_AHEAD) - and with that switched off
+    # the integrator CALLED the same way: one iteration per call and a wait after every call.  Twice: as the library serves such a
+    # caller by default - once it has seen the caller come back for the next image it keeps launches for the next calls in flight,
+    # each for up to four of them (ptmi_api.cpp: render_on_device, PTMI_RENDER_AHEAD, PTMI_RENDER_AHEAD_CALLS) - and with that
+    # switched off (one launch per call, nothing before the call).  The timed region starts and ends with an idle device
+    # (hipDeviceSynchronize), so what ran ahead before it and what is left running ahead after it cancel: as many iterations are
+    # rendered inside it as are asked for.
+    import torch
     def blocking_loop(ahead):
         os.environ["PTMI_RENDER_AHEAD"] = ahead
         try:
             be = pt.Backend().setup_context(W, H, D, scene.lightsSize, pt.structs.JITTERED, device=device, flags=flags)
             be.initialize_memory(scene)
-            for k in range(100, 103):  # warm-up; the third call already finds its launch in flight
+            for k in range(100, 116):  # warm-up: the caller is seen to come back, the launches ahead reach their full size
                 be.render(k, 1)
                 be.synchronize()
-            be.clear()
-            n_own = 16
+            torch.cuda.synchronize(device)
+            n_own = 32
             t0 = time.perf_counter()
-            for k in range(103, 103 + n_own):
+            for k in range(116, 116 + n_own):
                 be.render(k, 1)
                 be.synchronize()
+            torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
             be.release()
         finally:
@@ -491,10 +496,10 @@ def reference_kernel_leg(pt, scene, args, W, H, D, device, flags, batched_mpaths
     own_mpaths_no_ahead = blocking_loop("0")
     return {"Mpaths/s": ref_mpaths, "iterations": n_it, "work_group": "8x8", "kernel_ms_per_iteration": ms / n_it,
             "code_object": f"oracle/_ref/ref_kernel_{case}.hsaco (default build: the reference's own options)",
-            "integrator_one_iteration_per_launch_Mpaths/s": own_mpaths,
-            "ratio_at_equal_launch_counts": own_mpaths / ref_mpaths,
-            "integrator_one_iteration_per_launch_without_rendering_ahead_Mpaths/s": own_mpaths_no_ahead,
-            "ratio_at_equal_launch_counts_without_rendering_ahead": own_mpaths_no_ahead / ref_mpaths,
+            "integrator_one_iteration_per_call_blocking_Mpaths/s": own_mpaths,
+            "ratio_one_iteration_per_call_blocking": own_mpaths / ref_mpaths,
+            "integrator_one_iteration_per_launch_Mpaths/s": own_mpaths_no_ahead,
+            "ratio_at_equal_launch_counts": own_mpaths_no_ahead / ref_mpaths,
             "ratio_at_the_integrators_launch_size": batched_mpaths / ref_mpaths,
             "note": "same scene, same samples (in --arithmetic default the two kernels' images are equal bit for bit), same GPU, same "
                     "run; paths/s ratio = samples/s ratio (same segments per path)"}

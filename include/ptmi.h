@@ -142,6 +142,9 @@ typedef struct ptmi_scheduler_stats {
                                                 reference's literal loops (ptmi_literal_kernel_reason, below); counted ALWAYS, flag or not */
     uint64_t textured_hits;                  /* surface hits whose material has a file texture (one texel fetch each at least: the
                                                 4 * N_texel term of the algorithmic-bytes model); counted only while collecting */
+    uint64_t workgroup_lanes, resident_workgroups; /* the grid of the most recent wavefront-kernel launch on devices[0] (this context's
+                                                or another's): lanes per workgroup, and how many workgroups the device holds at once
+                                                - the persistent grid; 0 before the first launch; filled ALWAYS */
 } ptmi_scheduler_stats;
 
 /* The reference's device-side consistency checks: with -D LOG_INFO (OpenCL.cpp:310, globalVars.printLogInfos) its kernel

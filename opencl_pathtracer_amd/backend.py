@@ -70,7 +70,8 @@ class Counters(C.Structure):
 
 class SchedulerStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("trips_node", "lanes_node", "trips_triangle", "lanes_triangle", "trips_path",
-                                         "lanes_path", "cycles_path", "cycles_loop", "leaf_item_violations", "paths_retraced", "textured_hits")]
+                                         "lanes_path", "cycles_path", "cycles_loop", "leaf_item_violations", "paths_retraced", "textured_hits", "workgroup_lanes",
+                                         "resident_workgroups")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -171,6 +171,7 @@ struct DWarm {
     uint32_t russian_roulette;  // PTMI_FLAG_RUSSIAN_ROULETTE (non-parity mode)
     uint32_t source_seed;       // PTMI_FLAG_SOURCE_SEED (non-parity mode)
     uint32_t wait_debt;         // see PTMI_WF_WAIT_DEBT
+    uint32_t split_paths;       // DScene::split_paths
 };
 
 // A finished path's three histogram bins in one word: depth (6 bits, < kStatDepthBins), box tests and triangle tests
@@ -188,6 +189,22 @@ constexpr uint32_t kPoisonMarker = 0x7FC0DEADu;
 // rest keep the ordered minimum, as every such path did before round 4.
 constexpr uint32_t kGivenUp = 0x80000000u, kGiveUpListFirst = (uint32_t)(kQueues * kQueueStride), kGiveUpListCap = 8u * 1024u - kGiveUpListFirst;
 static_assert(kQueues * kQueueStride <= 1024, "the give-up list lies behind the queue counters inside the set's 8 x 1024 dwords");
+// A launch that renders AHEAD for several calls at once (DScene::split_paths = staging slots per call, ptmi_api.cpp) keeps the
+// totals of ptmi_get_counters per call: the paths of call k add theirs to block k - kSplitWords words each in LDS (PATHS .. TRI:
+// all a launch without scheduler statistics counts), C_COUNT words apart in the set's counter block.  Any other launch:
+// split_paths = 0, everything in block 0.  (The workgroup's LDS block is as large as before round 4 - 24 words, of which the
+// production instantiations used six: at 22 stack levels five workgroups fill a CU's LDS to the last allocation granule, and a
+// block of 48 words cost the fifth, 974 -> 882 Msamples/s.)
+constexpr uint32_t kSplitWords = C_TRI + 1;
+static_assert(PTMI_COUNTER_SPLITS * (int)kSplitWords <= 64, "flushed by one wave");
+__device__ __forceinline__ uint32_t counter_split_of(uint32_t slot, uint32_t split_paths)
+{
+    // (three compares instead of a division: at most PTMI_COUNTER_SPLITS = 4 calls share a launch)
+    const uint32_t t1 = split_paths ? split_paths : 0xFFFFFFFFu, t2 = split_paths ? 2u * split_paths : 0xFFFFFFFFu,
+                   t3 = split_paths ? 3u * split_paths : 0xFFFFFFFFu;
+    return (slot >= t1 ? 1u : 0u) + (slot >= t2 ? 1u : 0u) + (slot >= t3 ? 1u : 0u);
+}
+
 __device__ __forceinline__ uint32_t pack_path_statistics(uint32_t depth, uint32_t bbx, uint32_t tri)
 {
     static_assert(PTMI_MAX_INTERSECTION_NUMBER <= 8191, "13-bit fields");
@@ -240,10 +257,13 @@ __global__ void __launch_bounds__(BLOCK, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN
     constexpr int kWfBlock = BLOCK;  // (shadows the namespace's: every LDS stride below is the workgroup's own width)
     constexpr bool kTos = PTMI_WF_TOS == 1 || (PTMI_WF_TOS == 2 && !PLAIN);
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_mem[];
-    __shared__ unsigned long long block_counters[C_COUNT];
+    // (the statistics build: one block with every counter, its launches never render for several calls)
+    constexpr uint32_t kBlockCounters = STATS ? (uint32_t)C_COUNT : PTMI_COUNTER_SPLITS * kSplitWords;
+    static_assert(kBlockCounters <= 64, "zeroed and flushed by one wave");
+    __shared__ unsigned long long block_counters[kBlockCounters];
 
     const uint32_t tid = threadIdx.x;
-    if (tid < C_COUNT) block_counters[tid] = 0;
+    if (tid < kBlockCounters) block_counters[tid] = 0;
     __syncthreads();
     // LDS: [closest-hit record: 8][sentinel][stack levels...], each level one dword per lane.  The sentinel below the
     // stack holds REF_NONE: popping an empty stack yields "query finished" without a test (and, sitting behind the
@@ -332,7 +352,10 @@ __global__ void __launch_bounds__(BLOCK, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN
         // (the index goes through an opaque asm so that the compiler does not see a wave-uniform address: for those it sums
         // the lanes in a scalar loop first - five loops on the critical path of a pass in which two or three lanes finish.
         // Plain LDS atomics: 1M triangles +0.2 %, Cornell box +4.1 %, material mix +1.6 %)
-        uint32_t none = 0;
+        // (... and the call the path belongs to, when the launch renders ahead for several: counter_split_of)
+        uint32_t split_paths = sc.split_paths;
+        asm volatile("" : "+s"(split_paths));  // (the three thresholds are made HERE, not kept in scalar registers across the loops)
+        uint32_t none = STATS ? 0u : counter_split_of(slot, split_paths) * kSplitWords;
         asm volatile("" : "+v"(none));
         unsigned long long* const totals = &block_counters[none];
         atomicAdd(&totals[C_PATHS], 1ull);
@@ -1000,9 +1023,17 @@ __global__ void __launch_bounds__(BLOCK, PLAIN ? PTMI_WF_MIN_WAVES : PTMI_WF_MIN
     if (STATS && item_violations != 0u) atomicAdd(&block_counters[C_ITEM_VIOLATIONS], (unsigned long long)item_violations);
     __syncthreads();
     // every surface hit sends one shadow ray to every light (Scene_ComputeDirectIllumination, :901-954)
-    if (tid == 0) block_counters[C_SHADOW] = block_counters[C_HITS] * sc.n_lights;
+    if (tid < (STATS ? 1u : (uint32_t)PTMI_COUNTER_SPLITS)) {
+        unsigned long long* const totals = &block_counters[tid * kSplitWords];
+        totals[C_SHADOW] = totals[C_HITS] * sc.n_lights;
+    }
     __syncthreads();
-    if (tid < C_COUNT) atomicAdd(&cold_scene().counters[tid], block_counters[tid]);
+    if (STATS) {
+        if (tid < C_COUNT) atomicAdd(&cold_scene().counters[tid], block_counters[tid]);
+    } else if (tid < kBlockCounters) {
+        const uint32_t k = tid / kSplitWords, c = tid % kSplitWords;
+        if (k == 0u || block_counters[tid] != 0ull) atomicAdd(&cold_scene().counters[k * C_COUNT + c], block_counters[tid]);
+    }
 }
 
 // The paths a wavefront launch gave up (marked radiance in the staging slot, counted as one segment without a hit), traced
@@ -1021,10 +1052,11 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
 {
     if (__builtin_nontemporal_load(&job_counter[1]) == 0u) return;  // (the same for every lane of the grid)
     __shared__ uint32_t stack_mem[kStackDepth * kBlock];
-    __shared__ unsigned long long block_counters[C_TRI + 1];  // (two's complement: the one segment the launch counted is taken back)
+    // (two's complement: the one segment the launch counted is taken back; one block per call the launch rendered for)
+    __shared__ unsigned long long block_counters[PTMI_COUNTER_SPLITS * kSplitWords];
     __shared__ uint32_t queues[kBlock / 64][128];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    if (tid <= C_TRI) block_counters[tid] = 0;
+    if (tid < PTMI_COUNTER_SPLITS * kSplitWords) block_counters[tid] = 0;
     __syncthreads();
     const uint32_t n_pixels = sc.width * sc.height, n_slots = n_pixels * n_iterations;
     auto trace_slot = [&](const uint32_t slot) {
@@ -1045,12 +1077,13 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
             if (pc.tri < PTMI_MAX_INTERSECTION_NUMBER) atomicAdd(&sc.hist_tri[pc.tri], 1u);
         }
         // (the launch counted: one path, one segment, no hit)
-        atomicAdd(&block_counters[C_PATHS], 1ull);  // (here: paths traced again)
-        atomicAdd(&block_counters[C_SEGMENTS], (unsigned long long)n_seg - 1ull);
-        atomicAdd(&block_counters[C_HITS], (unsigned long long)depth);
-        atomicAdd(&block_counters[C_SHADOW], (unsigned long long)n_shadow);
-        atomicAdd(&block_counters[C_BBX], (unsigned long long)pc.bbx);
-        atomicAdd(&block_counters[C_TRI], (unsigned long long)pc.tri);
+        unsigned long long* const totals = &block_counters[counter_split_of(slot, sc.split_paths) * kSplitWords];
+        atomicAdd(&totals[C_PATHS], 1ull);  // (here: paths traced again)
+        atomicAdd(&totals[C_SEGMENTS], (unsigned long long)n_seg - 1ull);
+        atomicAdd(&totals[C_HITS], (unsigned long long)depth);
+        atomicAdd(&totals[C_SHADOW], (unsigned long long)n_shadow);
+        atomicAdd(&totals[C_BBX], (unsigned long long)pc.bbx);
+        atomicAdd(&totals[C_TRI], (unsigned long long)pc.tri);
     };
     uint32_t* const queue = queues[tid >> 6];
     uint32_t queued = 0;  // wave-uniform: slots waiting in this wave's queue (< 64 between two steps)
@@ -1080,8 +1113,11 @@ __global__ void __launch_bounds__(kBlock) redo_poisoned_kernel(const DScene sc, 
     }
     if (lane < queued) trace_slot(queue[lane]);
     __syncthreads();
-    if (tid > C_PATHS && tid <= C_TRI && block_counters[tid] != 0ull) atomicAdd(&sc.counters[tid], block_counters[tid]);
-    if (tid == C_PATHS && block_counters[tid] != 0ull) atomicAdd(&sc.counters[C_RETRACED], block_counters[tid]);
+    if (tid < PTMI_COUNTER_SPLITS * kSplitWords && block_counters[tid] != 0ull) {
+        const uint32_t k = tid / kSplitWords, c = tid % kSplitWords;
+        if (c > C_PATHS && c <= C_TRI) atomicAdd(&sc.counters[k * C_COUNT + c], block_counters[tid]);
+        if (c == C_PATHS) atomicAdd(&sc.counters[k * C_COUNT + C_RETRACED], block_counters[tid]);
+    }
 }
 
 // The RANDOM sampler's form of the above: the paths a launch gave up are LISTED in its job-counter block (kGivenUp); traced
@@ -1284,6 +1320,16 @@ static int resident_blocks_of(Kernel kernel, uint32_t stack_levels, int block)
     return per_cu * n_cu;
 }
 
+// the grid of the most recent wavefront launch per device: lanes per workgroup << 20 | workgroups the device holds at once
+// (ptmi_scheduler_stats.workgroup_lanes / resident_workgroups: what a test of "five wide workgroups per CU" reads)
+static std::atomic<uint32_t> g_last_grid[64];
+void PTMI_ARITH(last_wavefront_grid)(int device, uint32_t* lanes, uint32_t* resident)
+{
+    const uint32_t v = device >= 0 && device < 64 ? g_last_grid[device].load(std::memory_order_relaxed) : 0u;
+    *lanes = v >> 20;
+    *resident = v & 0xFFFFFu;
+}
+
 int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in_device_memory, uint32_t first_iteration,
                             uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter, uint32_t stack_levels,
                             bool scheduler_stats, float* stage, uint32_t* stage_stats, void* stream, std::string* err)
@@ -1317,6 +1363,7 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
         warm.wide_records = sc.wide_records;
         warm.russian_roulette = sc.russian_roulette;
         warm.source_seed = sc.source_seed;
+        warm.split_paths = sc.split_paths;
         constexpr int kMaxCachedDevices = 64;
         int device = 0;
         const bool cached_device = hipGetDevice(&device) == hipSuccess && device >= 0 && device < kMaxCachedDevices;
@@ -1335,6 +1382,7 @@ int PTMI_ARITH(launch_render_wavefront)(const DScene& sc, const DScene* scene_in
             resident = resident_blocks_of(kernel, lv, B);                                                                  \
             if (cached_device) resident_cache[device][lv].store(resident, std::memory_order_relaxed);                      \
         }                                                                                                                  \
+        if (cached_device) g_last_grid[device].store((uint32_t)(B) << 20 | (uint32_t)resident, std::memory_order_relaxed); \
         uint32_t nb = (n_jobs + (B) - 1) / (B);                                                                           \
         if (resident > 0 && nb > (uint32_t)resident) nb = (uint32_t)resident;                                             \
         hipLaunchKernelGGL(kernel, dim3(nb), dim3(B), wavefront_lds_bytes(lv, B), st, scene_in_device_memory, warm,        \

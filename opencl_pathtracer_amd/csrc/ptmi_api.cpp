@@ -71,10 +71,13 @@ struct DeviceState {
     hipEvent_t rendered[kStageSets] = {};         // recorded on launch_stream[i] behind the kernel
     hipEvent_t stage_free[kStageSets] = {};       // recorded on the main stream behind the accumulation
     hipEvent_t reuse_after[kStageSets] = {};      // what the set's next launch waits for: stage_free (adopted) or rendered (dropped)
-    unsigned long long* d_set_counters[kStageSets] = {};  // [C_COUNT] each
+    unsigned long long* d_set_counters[kStageSets] = {};  // [PTMI_COUNTER_SPLITS][C_COUNT] each: one block per call a launch renders for
     DScene* d_scene_set[kStageSets] = {};         // ds with .counters = the set's block
-    struct Ahead { uint32_t first, n, stride; int set; };
-    std::deque<Ahead> ahead;                      // launches in flight that no call has asked for yet, oldest first
+    // a launch that renders for `calls` calls of n iterations each (ids from `first` on), of which `taken` have come and adopted
+    // their part
+    struct Ahead { uint32_t first, n, stride; int set; uint32_t calls, taken; };
+    std::deque<Ahead> ahead;                      // launches in flight that calls have not (all) asked for yet, oldest first
+    uint32_t streak = 0;                          // calls in a row that continued where the previous one left off
     uint32_t next_set = 0;
     // the previous ptmi_render call on this device: launches only run ahead of a caller that has been SEEN to continue where
     // it left off (ids first + n, same n), so a caller that jumps around pays nothing
@@ -321,15 +324,16 @@ int upload_scene(ptmi_ctx* ctx, DeviceState& d, const Relayout& lay, const ptmi_
     // counters, then one set of job-queue counters per stage set (256-byte aligned, up to 8 x 1024 dwords apart), then the
     // stage sets' counter blocks and scene records
     constexpr size_t kCounterBlock = ((C_COUNT * 8 + 255) / 256) * 256, kSceneBlock = ((sizeof(DScene) + 255) / 256) * 256;
+    constexpr size_t kSetCounterBlock = ((PTMI_COUNTER_SPLITS * C_COUNT * 8 + 255) / 256) * 256;
     constexpr int kSets = DeviceState::kStageSets;
-    if (int rc = device_alloc(ctx, d, kCounterBlock + 256 + kSets * 8 * 1024 * 4 + kSets * kCounterBlock, &dk)) return rc;
+    if (int rc = device_alloc(ctx, d, kCounterBlock + 256 + kSets * 8 * 1024 * 4 + kSets * kSetCounterBlock, &dk)) return rc;
     if (int rc = device_alloc(ctx, d, (1 + kSets) * kSceneBlock, &dsc)) return rc;
     d.d_scene = (DScene*)dsc;
     d.d_color = (float*)dc; d.d_count = (float*)dn; d.d_hist = (uint32_t*)dh;
     d.d_counters = (unsigned long long*)dk;
     d.d_job_counter = (uint32_t*)((char*)dk + kCounterBlock);
     for (int i = 0; i < kSets; i++) {
-        d.d_set_counters[i] = (unsigned long long*)((char*)dk + kCounterBlock + kSets * 8 * 1024 * 4 + i * kCounterBlock);
+        d.d_set_counters[i] = (unsigned long long*)((char*)dk + kCounterBlock + kSets * 8 * 1024 * 4 + i * kSetCounterBlock);
         d.d_scene_set[i] = (DScene*)((char*)dsc + (1 + i) * kSceneBlock);
     }
 
@@ -456,7 +460,20 @@ int render_ahead_depth()
 {
     const char* e = std::getenv("PTMI_RENDER_AHEAD");  // (read per call: the tests switch it between contexts)
     const int v = e ? std::atoi(e) : 2;
-    return v < 0 ? 0 : (v > DeviceState::kStageSets - 1 ? DeviceState::kStageSets - 1 : v);
+    // (at most kStageSets - 2: beside them one launch whose calls are coming, and one set for a call that finds nothing)
+    return v < 0 ? 0 : (v > DeviceState::kStageSets - 2 ? DeviceState::kStageSets - 2 : v);
+}
+
+// ... and how many CALLS one of those launches may render for (PTMI_RENDER_AHEAD_CALLS, default PTMI_COUNTER_SPLITS = 4, 1 = one
+// launch per call): a persistent launch of ONE iteration spends a fifth of its time in its ragged end, and two such launches
+// side by side share the CUs only as the first one's workgroups retire - at the very end of that tail.  One launch for the next
+// four calls has one tail in four; each call adopts its quarter of the staging arrays and its own block of counters.
+constexpr uint32_t kAheadIterations = 4;  // iterations of such a launch at most (calls x iterations per call)
+uint32_t render_ahead_calls()
+{
+    const char* e = std::getenv("PTMI_RENDER_AHEAD_CALLS");
+    const int v = e ? std::atoi(e) : PTMI_COUNTER_SPLITS;
+    return v < 1 ? 1u : (v > PTMI_COUNTER_SPLITS ? (uint32_t)PTMI_COUNTER_SPLITS : (uint32_t)v);
 }
 
 // Stage set `set` able to hold `iterations` iterations (radiance float4 + one statistics word per path).  Growing it waits
@@ -504,8 +521,8 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
         const size_t want = n < ctx->iterations_per_launch ? n : ctx->iterations_per_launch;
         if (int rc = ensure_stage_set(ctx, d, 0, want)) return rc;
         if (may_overlap && (n % ctx->iterations_per_launch) != 0 && (n % ctx->iterations_per_launch) < kShort)
-            for (int i = 1; i < DeviceState::kStageSets; i++)
-                if (int rc = ensure_stage_set(ctx, d, i, kShort - 1)) return rc;
+            for (int i = can_run_ahead ? 0 : 1; i < DeviceState::kStageSets; i++)
+                if (int rc = ensure_stage_set(ctx, d, i, can_run_ahead && kAheadIterations > kShort - 1 ? kAheadIterations : kShort - 1)) return rc;
         for (int i = 0; i < DeviceState::kStageSets && may_overlap; i++) {
             if (!d.launch_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&d.launch_stream[i], hipStreamNonBlocking));
             if (!d.rendered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.rendered[i], hipEventDisableTiming));
@@ -529,19 +546,32 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     const bool stats_build = (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0;
     // where the statistics words of a set's launches go: staged per path and counted after the launch, unless there is no
     // histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
+    // a stage set no launch in flight ahead of the caller holds (there always is one: fewer launches ahead than sets)
+    auto pick_set = [&]() {
+        int set = 0;
+        for (int tries = 0; tries < DeviceState::kStageSets; tries++) {
+            set = (int)(d.next_set++ % DeviceState::kStageSets);
+            bool held = false;
+            for (const DeviceState::Ahead& a : d.ahead) held = held || a.set == set;
+            if (!held) break;
+        }
+        return set;
+    };
     auto stats_of = [&](int set) -> uint32_t* {
         if (!(d.d_stage[set] && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)) return nullptr;
         return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d.d_stage[set]) + d.stage_cap[set] * npix * 16);
     };
     // A SHORT launch on stage set `set`: on the set's own stream, counting into the set's own block - it touches nothing else
     // of the context, whether a call has asked for it or not.
-    auto launch_on_set = [&](int set, uint32_t f, uint32_t m) {
+    // `calls` > 1: the launch renders for that many calls of m / calls iterations each, and counts per call.
+    auto launch_on_set = [&](int set, uint32_t f, uint32_t m, uint32_t calls) {
         hipStream_t ls = d.launch_stream[set];
         if (d.reuse_after[set]) e = hipStreamWaitEvent(ls, d.reuse_after[set], 0);
-        if (e == hipSuccess) e = hipMemsetAsync(d.d_set_counters[set], 0, C_COUNT * 8, ls);
+        if (e == hipSuccess) e = hipMemsetAsync(d.d_set_counters[set], 0, PTMI_COUNTER_SPLITS * C_COUNT * 8, ls);
         if (e != hipSuccess) return;
         DScene on_set = d.ds;
         on_set.counters = d.d_set_counters[set];
+        on_set.split_paths = calls > 1 ? (uint32_t)((m / calls) * npix) : 0u;
         rc = KERNELS_OF(ctx, launch_render_wavefront)(on_set, d.d_scene_set[set], f, m, stride, d.d_job_counter + set * 8 * 1024, ctx->stack_levels,
                                                       stats_build, d.d_stage[set], stats_of(set), ls, &err);
         if (rc != PTMI_OK) return;
@@ -567,18 +597,21 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 // get in each other's way, and their ragged ends are 1 % of their length anyway)
                 const bool on_own_stream = may_overlap && m < kShort;
                 int set = 0;
+                uint32_t part = 0;  // which of the calls a launch that ran ahead rendered for this one is
                 if (on_own_stream) {
-                    // a launch that ran ahead of this call?  (the oldest first; anything else the caller did not come back for)
+                    // a launch that ran ahead for this call?  (the oldest first; anything else the caller did not come back for)
                     bool found = false;
                     while (can_run_ahead && !d.ahead.empty() && !found) {
-                        const DeviceState::Ahead a = d.ahead.front();
-                        d.ahead.pop_front();
-                        found = a.first == f && a.n == m && a.stride == stride;
+                        DeviceState::Ahead& a = d.ahead.front();
+                        found = a.n == m && a.stride == stride && (uint64_t)a.first + (uint64_t)a.taken * a.n * a.stride == (uint64_t)f;
                         set = a.set;
+                        part = a.taken;
+                        if (!found || ++a.taken == a.calls) d.ahead.pop_front();
                     }
                     if (!found) {
-                        set = (int)(d.next_set++ % DeviceState::kStageSets);
-                        launch_on_set(set, f, m);
+                        part = 0;
+                        set = pick_set();
+                        launch_on_set(set, f, m, 1);
                         if (rc != PTMI_OK || e != hipSuccess) break;
                     }
                     e = hipStreamWaitEvent(d.stream, d.rendered[set], 0);
@@ -591,8 +624,8 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     if (rc != PTMI_OK) break;
                     d.launches_issued++;
                 }
-                float* const stage = staged ? d.d_stage[set] : nullptr;
-                uint32_t* const stage_stats = staged ? stats_of(set) : nullptr;
+                float* const stage = staged ? d.d_stage[set] + (size_t)part * m * npix * 4 : nullptr;
+                uint32_t* const stage_stats = staged && stats_of(set) ? stats_of(set) + (size_t)part * m * npix : nullptr;
                 if (!plan) {
                     rc = KERNELS_OF(ctx, launch_accumulate_staged)(d.ds, f, m, stage, stage_stats, true, d.stream, &err);
                 } else {
@@ -611,7 +644,7 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     if (rc != PTMI_OK && err.empty()) err = ctx->err;
                 }
                 if (rc != PTMI_OK) break;
-                if (on_own_stream) rc = launch_add_counters(d.d_counters, d.d_set_counters[set], C_COUNT, d.stream, &err);
+                if (on_own_stream) rc = launch_add_counters(d.d_counters, d.d_set_counters[set] + (size_t)part * C_COUNT, C_COUNT, d.stream, &err);
                 if (rc != PTMI_OK) break;
                 if (staged && may_overlap) {  // (also behind a launch on the main stream: a later short launch may take set 0)
                     e = hipEventRecord(d.stage_free[set], d.stream);
@@ -627,14 +660,28 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
             // flight would only be in its way
             const bool caller_waits = d.previous_call_done == nullptr || hipEventQuery(d.previous_call_done) == hipSuccess;
             (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+            d.streak = continues ? d.streak + 1 : 0;
             if (can_run_ahead && continues && caller_waits && rc == PTMI_OK && e == hipSuccess) {
-                uint64_t next = d.ahead.empty() ? (uint64_t)first + (uint64_t)n * stride : (uint64_t)d.ahead.back().first + (uint64_t)n * stride;
-                while ((int)d.ahead.size() < render_ahead_depth() && next + (uint64_t)(n - 1) * stride <= 0xFFFFFFFFull &&
-                       rc == PTMI_OK && e == hipSuccess) {
-                    const int set = (int)(d.next_set++ % DeviceState::kStageSets);
-                    launch_on_set(set, (uint32_t)next, n);
-                    if (rc == PTMI_OK && e == hipSuccess) d.ahead.push_back({(uint32_t)next, n, stride, set});
-                    next += (uint64_t)n * stride;
+                uint64_t next = d.ahead.empty() ? (uint64_t)first + (uint64_t)n * stride
+                                                : (uint64_t)d.ahead.back().first + (uint64_t)d.ahead.back().calls * n * stride;
+                // (a launch whose calls have begun to come no longer counts: what replaces it starts as soon as it has ended)
+                const int untouched = (int)d.ahead.size() - (!d.ahead.empty() && d.ahead.front().taken != 0u ? 1 : 0);
+                // (Tried: the two launches ahead side by side with HALF of the persistent grid each, so that one's steady state fills
+                // the other's ragged end - 1M triangles 149.9 -> 132.4 Mpaths/s, Cornell box 1080p 1352 -> 1211: two persistent
+                // grids do not share the CUs evenly.  They take turns with whole grids.)
+                for (int have = untouched; have < render_ahead_depth() && rc == PTMI_OK && e == hipSuccess; have++) {
+                    // one launch for the next `calls` calls: as many as the caller has come back in a row, four iterations at most
+                    // (the statistics build counts per launch: one call each)
+                    uint32_t calls = stats_build ? 1u : render_ahead_calls();
+                    if (calls > kAheadIterations / n) calls = kAheadIterations / n;
+                    if (calls * n > ctx->iterations_per_launch) calls = ctx->iterations_per_launch / n;
+                    if (calls > d.streak) calls = d.streak;
+                    while (calls > 1 && next + ((uint64_t)calls * n - 1) * stride > 0xFFFFFFFFull) calls--;
+                    if (calls < 1 || next + (uint64_t)(n - 1) * stride > 0xFFFFFFFFull) break;
+                    const int set = pick_set();
+                    launch_on_set(set, (uint32_t)next, n * calls, calls);
+                    if (rc == PTMI_OK && e == hipSuccess) d.ahead.push_back({(uint32_t)next, n, stride, set, calls, 0u});
+                    next += (uint64_t)calls * n * stride;
                 }
             }
         }
@@ -1285,6 +1332,10 @@ int ptmi_get_scheduler_stats(ptmi_ctx* ctx, ptmi_scheduler_stats* out)
     out->leaf_item_violations = h[C_ITEM_VIOLATIONS];
     out->paths_retraced = h[C_RETRACED];
     out->textured_hits = h[C_TEXTURED_HITS];
+    uint32_t lanes = 0, resident = 0;
+    KERNELS_OF(ctx, last_wavefront_grid)(ctx->dev[0].device, &lanes, &resident);
+    out->workgroup_lanes = lanes;
+    out->resident_workgroups = resident;
     return PTMI_OK;
 }
 

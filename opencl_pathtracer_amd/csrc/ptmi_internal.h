@@ -90,6 +90,10 @@ struct DBigLeaf {
     uint32_t start, count;
 };
 
+// calls one launch may render AHEAD for (ptmi_api.cpp: render_on_device): the launch keeps the totals of ptmi_get_counters per
+// call, in as many blocks of C_COUNT words
+#define PTMI_COUNTER_SPLITS 4
+
 enum CounterSlot {
     C_PATHS = 0, C_SEGMENTS, C_HITS, C_SHADOW, C_BBX, C_TRI,
     // wave scheduler of the wavefront kernel: loop trips and active lanes per step kind
@@ -129,7 +133,8 @@ struct DScene {
     uint32_t* hist_depths;  // [D+1]   (nullptr = histograms off)
     uint32_t* hist_bbx;     // [5000]
     uint32_t* hist_tri;     // [5000]
-    unsigned long long* counters;  // [C_COUNT]
+    unsigned long long* counters;  // [C_COUNT]; [PTMI_COUNTER_SPLITS][C_COUNT] where split_paths != 0
+    uint32_t split_paths;          // 0, or: the launch renders for several calls, staging slots [k * split_paths, (k + 1) * split_paths) are call k's
     float* image_v;                // float4[W*H] global__imageV, only with SUPER_SAMPLING
     const float* x2inv;            // 1001-entry table, only with SUPER_SAMPLING
     float* stage_flag;             // float[W*H] per launch: 1 = path traced, 0 = skipped by the stop criterion
@@ -169,6 +174,7 @@ struct DScene {
                                         uint32_t n_iterations, uint32_t iteration_stride, uint32_t* job_counter,                \
                                         uint32_t stack_levels, bool scheduler_stats, float* stage,                              \
                                         uint32_t* stage_stats, void* stream, std::string* err);                                 \
+    void last_wavefront_grid##SUFFIX(int device, uint32_t* lanes_per_workgroup, uint32_t* resident_workgroups);                  \
     /* ... and what must follow it, in launch order: staged radiances -> accumulators, staged statistics -> histograms */       \
     int launch_accumulate_staged##SUFFIX(const DScene& sc, uint32_t first_iteration, uint32_t n_iterations, const float* stage,  \
                                          const uint32_t* stage_stats, bool with_histograms, void* stream, std::string* err);    \

@@ -134,6 +134,26 @@ def test_full_size_bit_exact_vs_reference_default_build(case):
     _assert_equal_to_reference(render_scene(sc, w, h, d, spp, sampler=sampler, flags=DA), ref, case)
 
 
+@pytest.mark.parametrize("name,w,h,d,lanes,waves_per_cu", [("tris1m", 1920, 1080, 10, 256, 20), ("mayalike", 3840, 2160, 16, 64, 17)])
+def test_persistent_grid_of_the_production_kernels(name, w, h, d, lanes, waves_per_cu):
+    """The headline scene's tree is 22 levels deep: five workgroups of 256 lanes fill a CU's LDS to the last allocation granule
+     - 192 bytes more of static LDS cost the fifth workgroup and 9 % in round 4, without a test noticing.  Deeper
+    trees (the configs[4] stand-in: 23 levels) run workgroups of 64 lanes, of which a CU holds 17 at least."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    sc = bvh_create(scenes.build(name, w, h))
+    be = backend.Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, flags=DA)
+    try:
+        be.initialize_memory(sc)
+        be.render(0, 1)
+        be.synchronize()
+        grid = be.scheduler_stats()
+    finally:
+        be.release()
+    assert grid["workgroup_lanes"] == lanes, grid
+    assert grid["resident_workgroups"] * lanes // 64 >= waves_per_cu * cus, (grid, cus)
+
+
 def test_the_one_bounce_the_reference_leaves_undefined():
     """The reference's water material refracts when random() >= its Fresnel fraction (cl:836-843).  On total internal reflection
     that fraction is 1 and Material_FresnelWaterReflectionFraction has returned (cl:237) BEFORE it writes the refraction direction

@@ -4,7 +4,9 @@ it waits, reads and shows, and every launch would pay its ramp-up and its ragged
 come back for the next ids (same count), ptmi_render keeps the launches of the next calls in flight before they are asked for
 (PTMI_RENDER_AHEAD, default 2), each on a stage set and with a counter block of its own, and ADOPTS one when its call comes -
 staged radiances into the accumulators, statistics words into the histograms, counters into the totals - or drops it without a
-trace when the caller asks for something else.  Invisible by construction; this file checks that it is."""
+trace when the caller asks for something else.  ONE such launch renders for up to four calls (PTMI_RENDER_AHEAD_CALLS, growing
+with the calls the caller has come back in a row): each call adopts its part of the staging arrays and its own block of the
+launch's counters.  Invisible by construction; this file checks that it is."""
 import numpy as np
 import pytest
 
@@ -16,9 +18,13 @@ pytestmark = pytest.mark.gpu
 DA = backend.FLAG_DEFAULT_ARITHMETIC
 
 
-def _play(sc, w, h, d, calls, flags, monkeypatch, ahead, sampler=S.JITTERED):
+def _play(sc, w, h, d, calls, flags, monkeypatch, ahead, sampler=S.JITTERED, calls_per_launch=None):
     """calls: ("render", first, n) | ("clear",) | ("read",) | ("counters",) -> list of what the reads returned + the final state"""
     monkeypatch.setenv("PTMI_RENDER_AHEAD", str(ahead))
+    if calls_per_launch is None:
+        monkeypatch.delenv("PTMI_RENDER_AHEAD_CALLS", raising=False)
+    else:
+        monkeypatch.setenv("PTMI_RENDER_AHEAD_CALLS", str(calls_per_launch))
     be = Backend().setup_context(w, h, d, sc.lightsSize, sampler, flags=flags)
     seen = []
     try:
@@ -66,6 +72,15 @@ SEQUENCES = {
               ("render", 9, 2), ("render", 11, 2), ("render", 13, 2), ("render", 20, 3), ("render", 23, 3), ("render", 26, 1), ("read",),
               ("render", 27, 40), ("render", 67, 1), ("render", 68, 1), ("clear",), ("render", 0, 1), ("render", 1, 1), ("render", 2, 1),
               ("render", 1, 1), ("render", 2, 1), ("render", 3, 1), ("counters",)],
+    # ... long enough for launches that render for four calls (the fourth launch ahead is the first of that size), the counters
+    # read after every call, the image now and then; then pairs (two calls per launch), a jump into the middle of a launch that
+    # ran ahead, and on
+    "one_by_one_long": [x for k in range(22) for x in ((("render", k, 1), ("counters",)) + ((("read",),) if k % 5 == 4 else ()))] +
+                       [x for k in range(6) for x in (("render", 22 + 2 * k, 2), ("counters",))] +
+                       [("render", 40, 1), ("render", 41, 1), ("render", 42, 1), ("render", 43, 1), ("render", 44, 1), ("render", 45, 1),
+                        ("render", 46, 1), ("render", 47, 1), ("render", 48, 1), ("render", 50, 1), ("counters",), ("render", 51, 1),
+                        ("render", 52, 1), ("render", 53, 1), ("render", 54, 1), ("render", 55, 1), ("render", 56, 1), ("clear",),
+                        ("render", 57, 1), ("render", 58, 1), ("counters",)],
     # pairs and triples in order
     "pairs_then_triples": [("render", 2 * k, 2) for k in range(5)] + [("render", 10 + 3 * k, 3) for k in range(4)],
 }
@@ -79,6 +94,8 @@ def test_rendering_ahead_is_invisible(case, name, scene_factory, monkeypatch):
     plain = _play(sc, w, h, d, SEQUENCES[name], DA, monkeypatch, ahead=0)
     for depth in (1, 2, 3):
         _same(_play(sc, w, h, d, SEQUENCES[name], DA, monkeypatch, ahead=depth), plain)
+    for calls_per_launch in (1, 2, 3):  # (above: the default, four)
+        _same(_play(sc, w, h, d, SEQUENCES[name], DA, monkeypatch, ahead=2, calls_per_launch=calls_per_launch), plain)
 
 
 def test_rendering_ahead_with_the_statistics_build_and_no_histograms(scene_factory, monkeypatch):
@@ -97,10 +114,14 @@ def test_rendering_ahead_of_paths_that_are_given_up(monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         wild = bvh_create(scenes.build("fuzz3h_l1", w, h))
-    a = _play(wild, w, h, d, SEQUENCES["one_by_one"], DA, monkeypatch, ahead=2)
     b = _play(wild, w, h, d, SEQUENCES["one_by_one"], DA, monkeypatch, ahead=0)
-    assert a[5] > 0
-    _same(a, b)
+    for calls_per_launch in (1, None):
+        a = _play(wild, w, h, d, SEQUENCES["one_by_one"], DA, monkeypatch, ahead=2, calls_per_launch=calls_per_launch)
+        assert a[5] > 0
+        _same(a, b)
+    # ... and in launches that render for four calls: every call gets the re-traced paths' counts of ITS iterations
+    long_run = [x for k in range(20) for x in (("render", k, 1), ("counters",))]
+    _same(_play(wild, w, h, d, long_run, DA, monkeypatch, ahead=2), _play(wild, w, h, d, long_run, DA, monkeypatch, ahead=0))
 
 
 def test_rendering_ahead_is_not_used_where_it_cannot_be(scene_factory, monkeypatch):

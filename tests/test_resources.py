@@ -38,7 +38,7 @@ def test_wavefront_kernel_keeps_five_waves_per_simd(arithmetic):
         nan_safe = key[4] == "1"  # (scenes whose records yield NaN distances: a few more live values, rare scenes - a little slack)
         assert figures["VGPRs Spill"] <= SPILL_BUDGET["plain" if key[3] == "1" else "general"] + (4 if nan_safe else 0), (key, figures)
         # the traversal loop (the depth-2 blocks) must not touch scratch: spills belong to the path-logic pass
-        assert figures["loop scratch"] <= (2 if nan_safe else 0), (key, figures)
+        assert figures["loop scratch"] <= (3 if nan_safe else 0), (key, figures)
     # the instrumented ones (<true, ...>: --scheduler-stats, SUPER_SAMPLING) carry more state and may reload a few words
     for key, figures in res.items():
         assert figures["VGPRs"] <= 96 and figures["Occupancy"] >= 5 and figures["loop scratch"] <= 12, (key, figures)
