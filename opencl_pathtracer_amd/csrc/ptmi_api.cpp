@@ -468,7 +468,9 @@ int render_ahead_depth()
 // launch per call): a persistent launch of ONE iteration spends a fifth of its time in its ragged end, and two such launches
 // side by side share the CUs only as the first one's workgroups retire - at the very end of that tail.  One launch for the next
 // four calls has one tail in four; each call adopts its quarter of the staging arrays and its own block of counters.
-constexpr uint32_t kAheadIterations = 4;  // iterations of such a launch at most (calls x iterations per call)
+// (Eight calls per launch would need eight blocks of totals in the workgroup's LDS, which has room for four: as 32-bit words with
+// a carry into memory they cost the kernel itself 1 - 3 %, 973 -> 965 Msamples/s on 1M triangles, material mix 2626 -> 2550.)
+constexpr uint32_t kAheadIterations = PTMI_COUNTER_SPLITS;  // iterations of such a launch at most (calls x iterations per call)
 uint32_t render_ahead_calls()
 {
     const char* e = std::getenv("PTMI_RENDER_AHEAD_CALLS");
@@ -516,13 +518,16 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     const bool can_run_ahead = may_overlap && render_ahead_depth() > 0 && !plan && n < kShort && ctx->n_dev() == 1 &&
                                !(d.ds.hist_depths && ctx->cfg.ray_max_depth >= 64);
     if (!can_run_ahead) d.ahead.clear();  // (their sets are free again once their kernels have ended: reuse_after)
+    // the caller comes back for the next ids with the same count
+    const bool continues = d.have_last && d.last_n == n && d.last_stride == stride &&
+                           (uint64_t)d.last_first + (uint64_t)n * stride == (uint64_t)first;
     if (staged) {
         // staging arrays: set 0 for the longest launch of this call, every set for a short one; grown on demand
         const size_t want = n < ctx->iterations_per_launch ? n : ctx->iterations_per_launch;
         if (int rc = ensure_stage_set(ctx, d, 0, want)) return rc;
         if (may_overlap && (n % ctx->iterations_per_launch) != 0 && (n % ctx->iterations_per_launch) < kShort)
-            for (int i = can_run_ahead ? 0 : 1; i < DeviceState::kStageSets; i++)
-                if (int rc = ensure_stage_set(ctx, d, i, can_run_ahead && kAheadIterations > kShort - 1 ? kAheadIterations : kShort - 1)) return rc;
+            for (int i = can_run_ahead && continues ? 0 : 1; i < DeviceState::kStageSets; i++)  // (room for launches ahead: only once they are due)
+                if (int rc = ensure_stage_set(ctx, d, i, can_run_ahead && continues && kAheadIterations > kShort - 1 ? kAheadIterations : kShort - 1)) return rc;
         for (int i = 0; i < DeviceState::kStageSets && may_overlap; i++) {
             if (!d.launch_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&d.launch_stream[i], hipStreamNonBlocking));
             if (!d.rendered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.rendered[i], hipEventDisableTiming));
@@ -653,8 +658,6 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 done += m;
             }
             // keep the next launches of a caller that comes back for one short call after the other in flight
-            const bool continues = d.have_last && d.last_n == n && d.last_stride == stride &&
-                                   (uint64_t)d.last_first + (uint64_t)n * stride == (uint64_t)first;
             // ... and only ahead of a caller that WAITS: if what the previous call asked for was still running when this call
             // came, the caller keeps the GPU busy by itself (launches queued ahead of its readbacks) and more launches in
             // flight would only be in its way
@@ -670,12 +673,12 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                 // the other's ragged end - 1M triangles 149.9 -> 132.4 Mpaths/s, Cornell box 1080p 1352 -> 1211: two persistent
                 // grids do not share the CUs evenly.  They take turns with whole grids.)
                 for (int have = untouched; have < render_ahead_depth() && rc == PTMI_OK && e == hipSuccess; have++) {
-                    // one launch for the next `calls` calls: as many as the caller has come back in a row, four iterations at most
+                    // one launch for the next `calls` calls: 1, 2, 4 as the caller keeps coming back, four iterations at most
                     // (the statistics build counts per launch: one call each)
                     uint32_t calls = stats_build ? 1u : render_ahead_calls();
                     if (calls > kAheadIterations / n) calls = kAheadIterations / n;
                     if (calls * n > ctx->iterations_per_launch) calls = ctx->iterations_per_launch / n;
-                    if (calls > d.streak) calls = d.streak;
+                    if (d.streak < 4 && calls > (1u << (d.streak - 1))) calls = 1u << (d.streak - 1);
                     while (calls > 1 && next + ((uint64_t)calls * n - 1) * stride > 0xFFFFFFFFull) calls--;
                     if (calls < 1 || next + (uint64_t)(n - 1) * stride > 0xFFFFFFFFull) break;
                     const int set = pick_set();

@@ -23,6 +23,15 @@ def pytest_collection_modifyitems(config, items):
     the run would still be green.  So their absence ends the session with an error, before any test runs."""
     if not any("gpu" in item.keywords for item in items) or not _hip_device_present():
         return
+    # torch's HIP runtime first: a few tests ask torch for device properties / free memory, and its runtime does not find the
+    # device when the library's (ctypes-loaded) one has initialised before it - which made those tests depend on which tests
+    # ran earlier in the session
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001  (no torch: those tests say so themselves)
+        pass
     import oracle_ffi
     if oracle_ffi.ALLOW_MISSING_REFERENCE:
         return
