@@ -1,7 +1,7 @@
 """Random sequences of C-ABI calls against a model of what they mean (GPU).
 
-The calls of include/ptmi.h in random order - renders of arbitrary iteration ranges, snapshots into arbitrary ring slots, bursts
-(ptmi_render_snapshots), reads of the image / a slot / the statistics / the counters, clears, re-uploads, image writes - on one
+The calls of include/ptmi.h in random order - renders of arbitrary iteration ranges, runs of short blocking calls in order (which the library
+renders ahead of), snapshots into arbitrary ring slots, bursts (ptmi_render_snapshots), reads of the image / a slot / the statistics / the counters, clears, re-uploads, image writes - on one
 device and on one device listed two or three times (the in-library multi-device path with its lazy snapshots and incremental
 peer copies).  The model: the accumulators are the sum of the per-iteration images rendered since the last clear / upload /
 write, a slot holds the accumulators as they were when its snapshot was queued; the per-iteration images come from the CPU
@@ -86,7 +86,26 @@ def test_random_call_sequences(seed, devices, per_iteration):
         be.initialize_memory(sc)
         for step in range(120):
             op = rs.choice(["render", "render", "render", "snapshot", "burst", "read_slot", "read_slot", "read_image", "statistics",
-                            "counters", "clear", "upload", "write", "sync", "kernel_time", "display", "pin"])
+                            "counters", "clear", "upload", "write", "sync", "kernel_time", "display", "pin", "walk"])
+            if op == "walk":
+                # the reference's loop for a while: one short call after the other, waiting for each - what the library renders
+                # AHEAD of (launches for the next calls, up to four calls each: tests/test_render_ahead_gpu.py) - with the counters or
+                # the image checked at a random call; the ops around it leave the pattern wherever they please
+                n = int(rs.choice([1, 1, 1, 2, 3]))
+                calls = int(rs.randint(2, 14))
+                first = int(rs.randint(0, N_IDS - calls * n + 1))
+                look = int(rs.randint(0, calls))
+                log.append(("walk", first, n, calls))
+                for c in range(calls):
+                    be.render(first + c * n, n)
+                    be.synchronize()
+                    for k in range(first + c * n, first + (c + 1) * n):
+                        m.add(k)
+                    if c == look and rs.rand() < 0.5:
+                        assert be.counters() == m.totals, (be.counters(), m.totals, log[-12:])
+                    elif c == look:
+                        same_image(be.read_image(), m.color, m.count, f"image at call {c} of a walk")
+                continue
             if op == "burst" and not bursts:
                 with pytest.raises(PtmiError):
                     be.render_snapshots(0, 2, 0)
