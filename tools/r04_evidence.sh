@@ -6,8 +6,9 @@
 #   part tris1m   : kernel trace + stats, one --pmc pass per counter group, scheduler statistics -> VALU cost model, the bench
 #                   line with all its legs, the strict-arithmetic line
 #   part mayalike : the same for the configs[4] stand-in (3840x2160, depth 16, 25 iterations per launch)
+#   part cornell  : the same for BASELINE configs[1] (Cornell box 1080p, depth 8)
 #   part configs  : BASELINE's other configs (tools/bench_configs.sh), the north-star parity check at full sizes and sample counts
-# usage: tools/r04_evidence.sh tris1m|mayalike|configs
+# usage: tools/r04_evidence.sh tris1m|mayalike|cornell|configs
 part=${1:?part}
 mkdir -p gpurun_out
 one_scene() {  # tag, general flag for the cost model, bench flags...
@@ -32,6 +33,8 @@ case $part in
     echo "== strict arithmetic"; python bench.py --steps 6 --warmup 1 --arithmetic strict --no-cpu-baseline --no-boundary > gpurun_out/r04_tris1m_bench_strict.json 2> gpurun_out/r04_tris1m_bench_strict.err;;
   mayalike)
     one_scene r04_mayalike "--general --narrow" --scene mayalike --width 3840 --height 2160 --depth 16 --spp-per-step 25;;
+  cornell)
+    one_scene r04_cornell "" --scene cornell --depth 8;;
   configs)
     bash tools/bench_configs.sh config0 config1 matmix tris4m
     echo "== north star at full sizes"; python tools/north_star_full_size.py tris1m cornell mayalike 2>&1 | grep -v "^{" | tail -8;;
