@@ -139,7 +139,10 @@ def test_persistent_grid_of_the_production_kernels(name, w, h, d, lanes, waves_p
     """The headline scene's tree is 22 levels deep: five workgroups of 256 lanes fill a CU's LDS to the last allocation granule
      - 192 bytes more of static LDS cost the fifth workgroup and 9 % in round 4, without a test noticing.  Deeper
     trees (the configs[4] stand-in: 23 levels) run workgroups of 64 lanes, of which a CU holds 17 at least."""
+    import os
     import torch
+    if lanes == 64 and os.environ.get("PTMI_GENERIC_TRIANGLES"):
+        pytest.skip("workgroups of 64 lanes exist for the two production instantiations only (precomputed triangle records)")
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     sc = bvh_create(scenes.build(name, w, h))
     be = backend.Backend().setup_context(w, h, d, sc.lightsSize, S.JITTERED, flags=DA)
