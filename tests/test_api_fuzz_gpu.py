@@ -6,6 +6,8 @@ device and on one device listed two or three times (the in-library multi-device 
 peer copies).  The model: the accumulators are the sum of the per-iteration images rendered since the last clear / upload /
 write, a slot holds the accumulators as they were when its snapshot was queued; the per-iteration images come from the CPU
 oracle.  One device: bit for bit.  Several: sample counts and statistics exactly, sums up to their association."""
+import os
+
 import numpy as np
 import pytest
 
@@ -56,7 +58,7 @@ class Model:
 
 
 @pytest.mark.parametrize("devices", [None, [0, 0], [0, 0, 0]], ids=["one", "two", "three"])
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTMI_API_FUZZ_SEEDS", "24"))))  # (a soak: PTMI_API_FUZZ_SEEDS=400)
 def test_random_call_sequences(seed, devices, per_iteration):
     rs = np.random.RandomState(1234 + seed)
     exact = devices is None
