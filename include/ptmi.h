@@ -191,10 +191,10 @@ int ptmi_initialize_memory(ptmi_ctx* ctx, const ptmi_scene* scene);
  * on the context's stream.
  * A caller that renders one short call (fewer than 4 iterations) after the other, in order, and waits for each - the
  * reference's loop - is RENDERED AHEAD OF: once the pattern has been seen the library keeps launches for the next calls in
- * flight (two, each for up to four calls), and a call that finds its iterations rendered adopts them.  Nothing a caller can
+ * flight (two per device, each for up to four calls), and a call that finds its iterations rendered adopts them.  Nothing a caller can
  * read differs from rendering on demand (image, sample counts, histograms, counters after every call); a call that leaves
- * the pattern drops what ran ahead.  Costs: up to 8 iterations of device time nobody asked for when such a caller stops, and
- * staging memory for 16 iterations (20 bytes per pixel each).  Environment: PTMI_RENDER_AHEAD=0 switches it off,
+ * the pattern drops what ran ahead.  Costs per device: up to 8 iterations of device time nobody asked for when such a caller
+ * stops, and staging memory for 16 iterations (20 bytes per pixel each).  Environment: PTMI_RENDER_AHEAD=0 switches it off,
  * PTMI_RENDER_AHEAD_CALLS=1 keeps it to one call per launch. */
 int ptmi_render(ptmi_ctx* ctx, uint32_t first_iteration, uint32_t n_iterations);
 

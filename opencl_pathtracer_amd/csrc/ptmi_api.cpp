@@ -513,9 +513,11 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     const bool may_overlap = staged && !ctx->cfg.super_sampling && d.stream == d.own_stream && !serial_env;
     const size_t npix = ctx->npix();
     constexpr uint32_t kShort = 4;  // launches of fewer iterations run beside their neighbours (see below)
-    // Rendering ahead: the call is ONE short launch of a single-device context, nothing but staged results leaves the kernel
-    // (the histograms of very deep paths are atomics inside it), and the caller has not asked for an image per iteration
-    const bool can_run_ahead = may_overlap && render_ahead_depth() > 0 && !plan && n < kShort && ctx->n_dev() == 1 &&
+    // Rendering ahead: the call is ONE short launch on this device, nothing but staged results leaves the kernel (the histograms
+    // of very deep paths are atomics inside it), and the caller has not asked for an image per iteration.  Per device: in a
+    // context of G devices a caller that asks for one image per call comes to this device with every G-th call (ids first,
+    // first + G, ...: the same pattern with stride G), and without launches ahead only ONE of the G devices would work at a time.
+    const bool can_run_ahead = may_overlap && render_ahead_depth() > 0 && !plan && n < kShort &&
                                !(d.ds.hist_depths && ctx->cfg.ray_max_depth >= 64);
     if (!can_run_ahead) d.ahead.clear();  // (their sets are free again once their kernels have ended: reuse_after)
     // the caller comes back for the next ids with the same count

@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 DA = backend.FLAG_DEFAULT_ARITHMETIC
 
 
-def _play(sc, w, h, d, calls, flags, monkeypatch, ahead, sampler=S.JITTERED, calls_per_launch=None):
+def _play(sc, w, h, d, calls, flags, monkeypatch, ahead, sampler=S.JITTERED, calls_per_launch=None, devices=None):
     """calls: ("render", first, n) | ("clear",) | ("read",) | ("counters",) -> list of what the reads returned + the final state"""
     monkeypatch.setenv("PTMI_RENDER_AHEAD", str(ahead))
     if calls_per_launch is None:
         monkeypatch.delenv("PTMI_RENDER_AHEAD_CALLS", raising=False)
     else:
         monkeypatch.setenv("PTMI_RENDER_AHEAD_CALLS", str(calls_per_launch))
-    be = Backend().setup_context(w, h, d, sc.lightsSize, sampler, flags=flags)
+    be = Backend().setup_context(w, h, d, sc.lightsSize, sampler, flags=flags, devices=devices)
     seen = []
     try:
         be.initialize_memory(sc)
@@ -124,9 +124,22 @@ def test_rendering_ahead_of_paths_that_are_given_up(monkeypatch):
     _same(_play(wild, w, h, d, long_run, DA, monkeypatch, ahead=2), _play(wild, w, h, d, long_run, DA, monkeypatch, ahead=0))
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]], ids=["two", "three"])
+def test_rendering_ahead_per_device_in_a_multi_device_context(devices, scene_factory, monkeypatch):
+    """A context of G devices gives device k the ids = k (mod G): a caller that asks for one image per call comes to each device
+    with every G-th call, and each device renders ahead of ITS calls (stride G) - without that only one of the G devices would
+    work at a time.  Same device list, with and without: every read, the counters after every call and the final state equal bit
+    for bit (the partial images are summed in device order either way)."""
+    scene, sampler, w, h, d = cases.CASES["matmix_96x96_d8"]
+    sc = scene_factory(scene, w, h)
+    for name in ("one_by_one_long", "jumps"):
+        _same(_play(sc, w, h, d, SEQUENCES[name], DA, monkeypatch, ahead=2, devices=devices),
+              _play(sc, w, h, d, SEQUENCES[name], DA, monkeypatch, ahead=0, devices=devices))
+
+
 def test_rendering_ahead_is_not_used_where_it_cannot_be(scene_factory, monkeypatch):
-    """RANDOM sampler (nothing staged), SUPER_SAMPLING (every iteration reads the accumulators), a device listed twice: the same
-    results as ever (the RANDOM sampler's float sums are atomic: counts and totals exactly, colours closely)."""
+    """RANDOM sampler (nothing staged), SUPER_SAMPLING (every iteration reads the accumulators); and a device listed twice against
+    one device: the same results as ever (the RANDOM sampler's float sums are atomic: counts and totals exactly, colours closely)."""
     scene, _, w, h, d = cases.CASES["cornell_64x48_d4"]
     sc = scene_factory(scene, w, h)
     calls = SEQUENCES["one_by_one"]
