@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Mpaths/s of a caller that asks for ONE image per call and waits for it (the reference's loop, OpenCL.cpp:76-107), with and
-without rendering ahead, and of 32 images per call.  usage: tools/blocking_rate.py [scene [W H depth]]   (PTMI_LIBRARY: a variant)"""
+without rendering ahead, and of 32 images per call.  usage: tools/blocking_rate.py [scene [W H depth]]   (PTMI_LIBRARY: a variant;
+BLOCKING_RATE_DEVICES=0,1,...: an in-library multi-device context, where each device renders ahead of its own calls)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +13,12 @@ sc = pt.bvh_create(pt.scenes.build(scene, W, H))
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so")
 out = {}
+DEVICES = [int(x) for x in os.environ["BLOCKING_RATE_DEVICES"].split(",")] if os.environ.get("BLOCKING_RATE_DEVICES") else None
 DEPTH = os.environ.get("BLOCKING_RATE_DEPTH", "2")  # launches kept in flight ahead of the caller
 for ahead, calls in ((DEPTH, "4"), (DEPTH, "2"), (DEPTH, "1"), ("0", "1")):
     os.environ["PTMI_RENDER_AHEAD"] = ahead
     os.environ["PTMI_RENDER_AHEAD_CALLS"] = calls
-    be = pt.Backend().setup_context(W, H, D, sc.lightsSize, flags=backend.FLAG_DEFAULT_ARITHMETIC)
+    be = pt.Backend().setup_context(W, H, D, sc.lightsSize, flags=backend.FLAG_DEFAULT_ARITHMETIC, devices=DEVICES)
     be.initialize_memory(sc)
     for k in range(100, 116):
         be.render(k, 1); be.synchronize()

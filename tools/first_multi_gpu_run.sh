@@ -40,6 +40,10 @@ print("   ok: ncclReduce over", n, "communicators equals the peer-copy sum", "(b
 PY
 echo "== 3. the reference's own PathTracer_Main over the shim on all devices (PTMI_DEVICES=all is the default)"
 if [ -x oracle/_ref/ref_main_driver ]; then PTMI_LOG=1 oracle/_ref/ref_main_driver 2>&1 | tail -5; else echo "   (oracle/_ref/ref_main_driver not built here: skipped)"; fi
+echo "== 3b. a caller that asks for one image per call and waits (the reference's loop) on all devices: each device renders ahead of its own calls"
+echo "   (expect about N times the one-device figure with launches ahead, the one-device figure without)"
+BLOCKING_RATE_DEVICES=$(seq -s, 0 $((N - 1))) python tools/blocking_rate.py tris1m
+python tools/blocking_rate.py tris1m
 echo "== 4. one process per GPU over RCCL: bench.py --gpus k, weak scaling, k = 1, 2, 4, ... <= $N"
 for k in 1 2 4 8; do
   [ $k -le $N ] || break
