@@ -528,8 +528,17 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
         const size_t want = n < ctx->iterations_per_launch ? n : ctx->iterations_per_launch;
         if (int rc = ensure_stage_set(ctx, d, 0, want)) return rc;
         if (may_overlap && (n % ctx->iterations_per_launch) != 0 && (n % ctx->iterations_per_launch) < kShort)
-            for (int i = can_run_ahead && continues ? 0 : 1; i < DeviceState::kStageSets; i++)  // (room for launches ahead: only once they are due)
-                if (int rc = ensure_stage_set(ctx, d, i, can_run_ahead && continues && kAheadIterations > kShort - 1 ? kAheadIterations : kShort - 1)) return rc;
+            for (int i = can_run_ahead && continues ? 0 : 1; i < DeviceState::kStageSets; i++) {
+                // (room for launches ahead of several calls: only once they are due, and only if the device has it - a launch
+                // ahead renders for as many calls as its set holds)
+                const size_t small = kShort - 1, large = can_run_ahead && continues && kAheadIterations > small ? kAheadIterations : small;
+                int rc = ensure_stage_set(ctx, d, i, large);
+                if (rc != PTMI_OK && large > small) {
+                    (void)hipGetLastError();
+                    rc = ensure_stage_set(ctx, d, i, small);
+                }
+                if (rc != PTMI_OK) return rc;
+            }
         for (int i = 0; i < DeviceState::kStageSets && may_overlap; i++) {
             if (!d.launch_stream[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&d.launch_stream[i], hipStreamNonBlocking));
             if (!d.rendered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&d.rendered[i], hipEventDisableTiming));
@@ -684,6 +693,8 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
                     while (calls > 1 && next + ((uint64_t)calls * n - 1) * stride > 0xFFFFFFFFull) calls--;
                     if (calls < 1 || next + (uint64_t)(n - 1) * stride > 0xFFFFFFFFull) break;
                     const int set = pick_set();
+                    if ((size_t)n * calls > d.stage_cap[set]) calls = (uint32_t)(d.stage_cap[set] / n);
+                    if (calls < 1) break;
                     launch_on_set(set, (uint32_t)next, n * calls, calls);
                     if (rc == PTMI_OK && e == hipSuccess) d.ahead.push_back({(uint32_t)next, n, stride, set, calls, 0u});
                     next += (uint64_t)calls * n * stride;
