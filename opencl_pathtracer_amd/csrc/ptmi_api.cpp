@@ -560,8 +560,6 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
     int rc = PTMI_OK;
     hipError_t e = hipSuccess;
     const bool stats_build = (ctx->cfg.flags & PTMI_FLAG_SCHEDULER_STATS) != 0;
-    // where the statistics words of a set's launches go: staged per path and counted after the launch, unless there is no
-    // histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
     // a stage set no launch in flight ahead of the caller holds (there always is one: fewer launches ahead than sets)
     auto pick_set = [&]() {
         int set = 0;
@@ -573,6 +571,8 @@ int render_on_device(ptmi_ctx* ctx, DeviceState& d, uint32_t first, uint32_t n, 
         }
         return set;
     };
+    // where the statistics words of a set's launches go: staged per path and counted after the launch, unless there is no
+    // histogram (PTMI_FLAG_NO_HISTOGRAMS) or a depth that does not fit the 6-bit field
     auto stats_of = [&](int set) -> uint32_t* {
         if (!(d.d_stage[set] && d.ds.hist_depths && ctx->cfg.ray_max_depth < 64)) return nullptr;
         return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d.d_stage[set]) + d.stage_cap[set] * npix * 16);
