@@ -37,8 +37,10 @@ bool texture_ok(const ptmi_texture& t, uint32_t data_size)
 //   * the RAY is not a number (a refraction at |cos| = 1 + 1 ulp, cl:235; an origin that overflowed): the wavefront kernel
 //     checks every ray it sets up, gives such a path up and the literal loops trace it again into its staging slot
 //     (kernel_wavefront.hip: redo_poisoned_kernel) - costs nothing in the traversal loop;
-//   * the RECORDS are: then the whole scene is rendered by the one-path-per-lane kernel (a test per accepted triangle in
-//     the leaf pass would find them, and costs 0.9 % on every scene: measured, not kept).  This function finds those scenes.
+//   * the RECORDS are: then the scene runs the wavefront kernel's NANSAFE instantiation (round 4; before: the one-path-per-lane
+//     kernel for the whole scene) - a test per accepted triangle in the leaf pass, which hands only the paths that REACH such a
+//     record to the literal loops (0.9 % when every scene pays it: so only these scenes do).  This function finds those scenes;
+//     the one-path-per-lane kernel still renders them as a whole with the RANDOM sampler (nothing staged to patch).
 // With finite rays from origins below 2^40 a distance is a number when
 //   * every triangle's vertices, normals and vertex normals, the lights' positions and directions and the camera are finite
 //     and at most 2^21 (normals: 16) in magnitude: then the plane terms are finite, the ray parameter is (|N.d| >= 1e-5 or
